@@ -1,0 +1,129 @@
+/*
+ * bpp_abi.h -- C ABI of the MI355X-native vectorised 3D bin-packing environment step.
+ *
+ * The reference (alexfrom0815/Online-3D-BPP-DRL) is pure Python and has no FFI; this header is the
+ * boundary a maintainer would bind with ctypes.  Every entry point names the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Two shared libraries export exactly these symbols:
+ *   libbpp_hip.so     (online-3d-bpp-drl_amd/csrc)  all pointers are DEVICE pointers, `stream` is a
+ *                                                   hipStream_t; the product.
+ *   libbpp_oracle.so  (oracle/)                     all pointers are HOST pointers, `stream` ignored;
+ *                                                   test infrastructure only (the parity checker).
+ *
+ * Ownership: the caller allocates and owns every buffer (PyTorch-ROCm tensors in practice); the
+ * library never allocates or frees device memory and keeps no global state besides the thread-local
+ * last-error string.  Kernels are enqueued on `stream` and the calls return without synchronising.
+ *
+ * Error convention: 0 = success; >0 = hipError_t from the runtime; <0 = BPP_E_* below.  A message
+ * is available from bpp_last_error().  An infeasible or out-of-range *action* is not an error: it
+ * ends the episode with reward 0 exactly as envs/bpp0/bin3D.py:108-112 does.
+ */
+#ifndef BPP_ABI_H
+#define BPP_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPP_ABI_VERSION 1
+
+#define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
+#define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
+
+/* Which feasibility rule a mask is built with. */
+#define BPP_RULE_UTILS 0 /* acktr/utils.py:8-35   check_box -- the mask the ACKTR loop consumes   */
+#define BPP_RULE_SPACE 1 /* envs/bpp0/space.py:111-144 Space.check_box -- the placement rule, also
+                            used by PackingGame.get_possible_position (envs/bpp0/bin3D.py:72-93)  */
+
+/* bpp_reset modes */
+#define BPP_RESET_INIT    0 /* first reset: episode index 0                                        */
+#define BPP_RESET_ADVANCE 1 /* later VecEnv.reset(): every bin abandons its episode, next sequence */
+
+/* Per-bin scalar state, 32 bytes, array-of-structs so one bin's record is two 16-byte accesses.
+ * Replaces the Python objects hanging off one PackingGame + its bench.Monitor wrapper. */
+typedef struct bpp_env_state {
+    int32_t cursor;   /* index of `next_box` in the current sequence: BoxCreator FIFO head,
+                         envs/bpp0/binCreator.py:15-22, envs/bpp0/bin3D.py:68-70                   */
+    int32_t episode;  /* episodes finished by this bin (= creator resets - 1)                      */
+    int32_t n_boxes;  /* len(space.boxes), envs/bpp0/space.py:23,176                              */
+    int32_t vol_sum;  /* sum of x*y*z over placed boxes, envs/bpp0/space.py:146-151                */
+    double  ep_ret;   /* bench.Monitor running sum(self.rewards), baselines/bench/monitor.py:58-62 */
+    int32_t ep_len;   /* bench.Monitor len(self.rewards), baselines/bench/monitor.py:63            */
+    int32_t reserved;
+} bpp_env_state;
+
+/* One shard of bins living on one device.  Replaces N x (PackingGame + Space + BoxCreator +
+ * Monitor) behind ShmemVecEnv (acktr/envs.py:77-118, baselines/common/vec_env/shmem_vec_env.py). */
+typedef struct bpp_batch {
+    int32_t num_envs;      /* E: bins in this shard                                               */
+    int32_t W, L, H;       /* container_size, envs/bpp0/bin3D.py:10-16                             */
+    int32_t rotation;      /* enable_rotation: action/mask length M = W*L*(1+rotation), :35-38     */
+    int32_t mask_rule;     /* rule of the mask written by bpp_reset/bpp_step (BPP_RULE_*)          */
+    int32_t pool_size;     /* P: sequences in the pool                                             */
+    int32_t pool_len;      /* T: entries per sequence, padded; the LAST entry of every sequence is
+                              a terminator item and is what a cursor >= T keeps returning          */
+    int64_t env_id_base;   /* global id of this shard's bin 0 (multi-GPU: rank * E)                */
+    int64_t env_id_total;  /* bins in the whole job; episode k of global bin g plays sequence
+                              (g + k * env_id_total) mod P, independent of the GPU count           */
+    const uint8_t *seq_pool; /* [P][T][4] = (x, y, z, 0) item sizes                                */
+    int32_t *hmap;         /* [E][W*L] Space.plain, row-major idx = lx*L + ly,
+                              envs/bpp0/space.py:22,153-156                                        */
+    bpp_env_state *state;  /* [E]                                                                  */
+} bpp_batch;
+
+/* Outputs of one lock-step.  Layout = what VecPyTorch hands the ACKTR loop (acktr/envs.py:170-193)
+ * plus the location mask the loop builds per observation (main.py:122-129,163-169). */
+typedef struct bpp_step_out {
+    float   *obs;      /* [E][4*W*L] float32: planes hmap, x, y, z; envs/bpp0/bin3D.py:49-66; after a
+                          terminal step it is the NEXT episode's first observation
+                          (baselines/common/vec_env/shmem_vec_env.py:126-130)                      */
+    float   *mask;     /* [E][M] float32 0/1 for `obs`; all-ones when nothing is feasible
+                          (acktr/utils.py:59-60,91-92).  May be NULL (mask not wanted).            */
+    float   *reward;   /* [E] float32( float64(x*y*z / (W*L*H)) * 10 ), 0 on failure; bin3D.py:108-121 */
+    uint8_t *done;     /* [E] 1 iff the placement failed (episode over); bin3D.py:108-112          */
+    int32_t *counter;  /* [E] info['counter'] of the bin the action was applied to; bin3D.py:111,124 */
+    double  *ratio;    /* [E] info['ratio'] (before any auto-reset); bin3D.py:111,125              */
+    double  *ep_ret;   /* [E] where done: info['episode']['r'] before round(.,6); else running sum */
+    int32_t *ep_len;   /* [E] where done: info['episode']['l']; else running length                */
+} bpp_step_out;
+
+int bpp_abi_version(void);
+const char *bpp_last_error(void);
+/* out[0] = max W*L supported, out[1] = max H supported. */
+int bpp_limits(int32_t out[2]);
+
+/* VecEnv.reset(): zero every heightmap, restart every creator/Monitor, emit first obs (+mask).
+ * Replaces PackingGame.reset (envs/bpp0/bin3D.py:55-59) over all workers
+ * (baselines/common/vec_env/shmem_vec_env.py:61-67).  Only obs and mask of `out` are written. */
+int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream);
+
+/* VecEnv.step(actions): one lock-step of all bins, fused: action decode incl. the `idx > area`
+ * rotation quirk (bin3D.py:96-105), placement rule (space.py:111-144), heightmap update
+ * (space.py:36-46,164-181), reward (bin3D.py:44-46,114-121), info (bin3D.py:111,123-125), Monitor
+ * (baselines/bench/monitor.py:51-77), auto-reset (shmem_vec_env.py:126-130), next observation
+ * (bin3D.py:61-66) and its feasibility mask (acktr/utils.py:37-94).  actions: [E] int64. */
+int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *stream);
+
+/* Batched drop-in for acktr.utils.get_possible_position (rotation=0, acktr/utils.py:37-62) and
+ * get_rotation_mask (rotation=1, :64-94) on a [E][4*W*L] float32 observation batch. */
+int bpp_mask_from_obs(const float *obs, float *mask, int32_t E, int32_t W, int32_t L, int32_t H,
+                      int32_t rotation, int32_t rule, void *stream);
+
+/* Same from a raw int32 heightmap batch + items [E][3] (x,y,z): rule=BPP_RULE_SPACE, rotation=0
+ * is PackingGame.get_possible_position (envs/bpp0/bin3D.py:72-93). */
+int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, int32_t E, int32_t W,
+                       int32_t L, int32_t H, int32_t rotation, int32_t rule, void *stream);
+
+/* Benchmark/test action source (no reference counterpart; SURVEY.md 8d "actions for timing"):
+ * uniform choice among mask==1 entries with a counter-based RNG keyed by (seed, global bin id,
+ * step).  actions: [E] int64. */
+int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
+                        uint64_t seed, uint64_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPP_ABI_H */

@@ -1,0 +1,326 @@
+/*
+ * bpp_oracle.c -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference environment step, used only as the
+ * parity checker (tests/, __graft_entry__.smoke()) and as the `cpu_baseline` leg of bench.py.
+ * The product path (libbpp_hip.so) never links, loads or calls this file.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against golden vectors
+ * recorded from the unmodified reference Python (tests/golden/make_golden.py, run in the build
+ * container where /root/reference exists) and tests/test_oracle_vs_reference.py re-runs the live
+ * reference beside it when the reference tree is present.
+ *
+ * It deliberately follows the reference's arithmetic literally (float64 ratio compares, float64
+ * reward), not the integer rewrites the HIP kernels use, so that agreement HIP == oracle also
+ * validates those rewrites.  Paths below are relative to the reference root.
+ */
+#include "../include/bpp_abi.h"
+
+#include <stdio.h>
+#include <string.h>
+
+static __thread char g_err[256];
+
+static int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int bpp_abi_version(void) { return BPP_ABI_VERSION; }
+const char *bpp_last_error(void) { return g_err; }
+int bpp_limits(int32_t out[2]) {
+    if (!out) return fail(BPP_E_BADARG, "bpp_limits: NULL");
+    out[0] = 1 << 20;
+    out[1] = 255;
+    return 0;
+}
+
+/* acktr/utils.py:8-35  check_box(plain, x, y, lx, ly, z, container_size) -- mask rule "U". */
+static int check_box_utils(const int32_t *plain, int W, int L, int H, int x, int y, int lx, int ly, int z) {
+    if (lx + x > W || ly + y > L) return -1;            /* :9-10 */
+    if (lx < 0 || ly < 0) return -1;                    /* :11-12 */
+    int max_h = plain[lx * L + ly];                     /* :14-15 np.max(rec) */
+    for (int i = lx; i < lx + x; ++i)
+        for (int j = ly; j < ly + y; ++j)
+            if (plain[i * L + j] > max_h) max_h = plain[i * L + j];
+    int max_area = 0;                                   /* :16 np.sum(rec == max_h) */
+    for (int i = lx; i < lx + x; ++i)
+        for (int j = ly; j < ly + y; ++j)
+            max_area += (plain[i * L + j] == max_h);
+    int area = x * y;                                   /* :17 */
+    if (max_h + z > H) return -1;                       /* :20-21 */
+    int LU = plain[lx * L + ly] == max_h;               /* :23-26 */
+    int LD = plain[(lx + x - 1) * L + ly] == max_h;
+    int RU = plain[lx * L + ly + y - 1] == max_h;
+    int RD = plain[(lx + x - 1) * L + ly + y - 1] == max_h;
+    double r = (double)max_area / (double)area;         /* Python true division */
+    if (r > 0.95) return max_h;                         /* :28-29 */
+    if (LU + LD + RU + RD == 3 && r > 0.85) return max_h; /* :30-31 */
+    if (LU + LD + RU + RD == 4 && r > 0.50) return max_h; /* :32-33 */
+    return -1;
+}
+
+/* envs/bpp0/space.py:111-144  Space.check_box -- placement rule "S". */
+static int check_box_space(const int32_t *plain, int W, int L, int H, int x, int y, int lx, int ly, int z) {
+    if (lx + x > W || ly + y > L) return -1;            /* :112-113 */
+    if (lx < 0 || ly < 0) return -1;                    /* :114-115 */
+    int r00 = plain[lx * L + ly];                       /* :117-121 */
+    int r10 = plain[(lx + x - 1) * L + ly];
+    int r01 = plain[lx * L + ly + y - 1];
+    int r11 = plain[(lx + x - 1) * L + ly + y - 1];
+    int rm = r00;                                       /* :122 */
+    if (r10 > rm) rm = r10;
+    if (r01 > rm) rm = r01;
+    if (r11 > rm) rm = r11;
+    int sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm); /* :123 */
+    if (sc < 3) return -1;                              /* :124-125 */
+    int max_h = r00;                                    /* :127 */
+    for (int i = lx; i < lx + x; ++i)
+        for (int j = ly; j < ly + y; ++j)
+            if (plain[i * L + j] > max_h) max_h = plain[i * L + j];
+    int max_area = 0;                                   /* :129 */
+    for (int i = lx; i < lx + x; ++i)
+        for (int j = ly; j < ly + y; ++j)
+            max_area += (plain[i * L + j] == max_h);
+    int area = x * y;                                   /* :130 */
+    if (max_h + z > H) return -1;                       /* :134-135 */
+    double r = (double)max_area / (double)area;
+    if (r > 0.95) return max_h;                         /* :137-138 */
+    if (rm == max_h && sc == 3 && r > 0.85) return max_h; /* :139-140 */
+    if (rm == max_h && sc == 4 && r > 0.50) return max_h; /* :141-142 */
+    return -1;
+}
+
+static int check_box(int rule, const int32_t *plain, int W, int L, int H, int x, int y, int lx, int ly, int z) {
+    return rule == BPP_RULE_SPACE ? check_box_space(plain, W, L, H, x, y, lx, ly, z)
+                                  : check_box_utils(plain, W, L, H, x, y, lx, ly, z);
+}
+
+/* acktr/utils.py:37-62 get_possible_position and :64-94 get_rotation_mask (rule U), or
+ * envs/bpp0/bin3D.py:72-93 (rule S, rotation=0).  Writes float32 0/1 of length A*(1+rotation). */
+static void build_mask(int rule, const int32_t *plain, int W, int L, int H, int x, int y, int z, int rotation,
+                       float *mask) {
+    int A = W * L, M = A * (1 + rotation), sum = 0;
+    for (int k = 0; k < M; ++k) mask[k] = 0.0f;
+    for (int i = 0; i < W - x + 1; ++i)                 /* utils.py:54-57 / :76-79 */
+        for (int j = 0; j < L - y + 1; ++j)
+            if (check_box(rule, plain, W, L, H, x, y, i, j, z) >= 0) {
+                mask[i * L + j] = 1.0f;
+                ++sum;
+            }
+    if (rotation)
+        for (int i = 0; i < W - y + 1; ++i)             /* utils.py:81-84 */
+            for (int j = 0; j < L - x + 1; ++j)
+                if (check_box(rule, plain, W, L, H, y, x, i, j, z) >= 0) {
+                    mask[A + i * L + j] = 1.0f;         /* :86 hstack */
+                    ++sum;
+                }
+    if (sum == 0)                                       /* utils.py:59-60 / :91-92 */
+        for (int k = 0; k < M; ++k) mask[k] = 1.0f;
+}
+
+static int check_batch(const bpp_batch *b) {
+    if (!b || !b->seq_pool || !b->hmap || !b->state) return fail(BPP_E_BADARG, "bpp_batch: NULL pointer");
+    if (b->num_envs <= 0 || b->W <= 0 || b->L <= 0 || b->H <= 0 || b->pool_size <= 0 || b->pool_len <= 0)
+        return fail(BPP_E_BADARG, "bpp_batch: non-positive size");
+    if (b->env_id_total < b->env_id_base + b->num_envs) return fail(BPP_E_BADARG, "bpp_batch: env_id_total too small");
+    if (b->mask_rule != BPP_RULE_UTILS && b->mask_rule != BPP_RULE_SPACE) return fail(BPP_E_BADARG, "bpp_batch: bad mask_rule");
+    if (b->H > 255) return fail(BPP_E_TOOLARGE, "bpp_batch: H > 255");
+    return 0;
+}
+
+/* BoxCreator.preview(1)[0] (envs/bpp0/binCreator.py:15-18) on the pooled sequence this bin plays. */
+static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item[3]) {
+    int64_t gid = b->env_id_base + e;
+    int64_t seq = (gid + (int64_t)s->episode * b->env_id_total) % b->pool_size;
+    int c = s->cursor < b->pool_len ? s->cursor : b->pool_len - 1;
+    const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
+    item[0] = p[0];
+    item[1] = p[1];
+    item[2] = p[2];
+}
+
+/* PackingGame.cur_observation (envs/bpp0/bin3D.py:61-66) as float32 (shmem_vec_env.py:42-43) + mask. */
+static void write_obs_mask(const bpp_batch *b, int e, const int item[3], const bpp_step_out *out) {
+    int A = b->W * b->L, M = A * (1 + b->rotation);
+    const int32_t *plain = b->hmap + (size_t)e * A;
+    float *o = out->obs + (size_t)e * 4 * A;
+    for (int k = 0; k < A; ++k) {
+        o[k] = (float)plain[k];
+        o[A + k] = (float)item[0];                      /* bin3D.py:49-53 */
+        o[2 * A + k] = (float)item[1];
+        o[3 * A + k] = (float)item[2];
+    }
+    if (out->mask)
+        build_mask(b->mask_rule, plain, b->W, b->L, b->H, item[0], item[1], item[2], b->rotation,
+                   out->mask + (size_t)e * M);
+}
+
+/* PackingGame.reset (bin3D.py:55-59) + Monitor.reset_state (bench/monitor.py:45-49). */
+static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
+    int A = b->W * b->L;
+    memset(b->hmap + (size_t)e * A, 0, sizeof(int32_t) * A); /* space.py:22 */
+    s->cursor = 0;
+    s->n_boxes = 0;
+    s->vol_sum = 0;
+    s->ep_ret = 0.0;
+    s->ep_len = 0;
+    s->reserved = 0;
+}
+
+int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream) {
+    (void)stream;
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!out || !out->obs) return fail(BPP_E_BADARG, "bpp_reset: NULL obs");
+    if (mode != BPP_RESET_INIT && mode != BPP_RESET_ADVANCE) return fail(BPP_E_BADARG, "bpp_reset: bad mode");
+    for (int e = 0; e < b->num_envs; ++e) {
+        bpp_env_state *s = b->state + e;
+        s->episode = mode == BPP_RESET_INIT ? 0 : s->episode + 1;
+        reset_bin(b, e, s);
+        int item[3];
+        next_box(b, e, s, item);
+        write_obs_mask(b, e, item, out);
+    }
+    return 0;
+}
+
+int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *stream) {
+    (void)stream;
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->done || !out->counter || !out->ratio ||
+        !out->ep_ret || !out->ep_len)
+        return fail(BPP_E_BADARG, "bpp_step: NULL pointer");
+    const int W = b->W, L = b->L, H = b->H, A = W * L;
+    for (int e = 0; e < b->num_envs; ++e) {
+        bpp_env_state *s = b->state + e;
+        int32_t *plain = b->hmap + (size_t)e * A;
+        int item[3];
+        next_box(b, e, s, item);
+        /* bin3D.py:96-105 */
+        int64_t idx = actions[e];
+        int flag = 0;
+        if (idx > A && b->rotation) {                   /* strict '>' : quirk A.6-1.  With rotation off
+                                                           the reference asserts; such an index is outside
+                                                           the action space and is left to land out of
+                                                           bounds below (lx >= W). */
+            idx -= A;
+            flag = 1;
+        }
+        /* space.py:164-172 */
+        int x = flag ? item[1] : item[0];
+        int y = flag ? item[0] : item[1];
+        int z = item[2];
+        int new_h = -1;
+        /* space.py:153-156 idx_to_position.  A negative idx floors to lx < 0 in Python -> -1;
+           idx >= (W+1)*L is out of bounds whatever the item -> -1 (also keeps lx in int range). */
+        if (idx >= 0 && idx < (int64_t)(W + 1) * L)
+            new_h = check_box_space(plain, W, L, H, x, y, (int)(idx / L), (int)(idx % L), z);
+        double binvol = (double)W * (double)L * (double)H;
+        double reward;
+        int done;
+        if (new_h != -1) {
+            /* space.py:175-178 + update_height_graph :36-46 */
+            int lx = (int)(idx / L), ly = (int)(idx % L);
+            int max_h = plain[lx * L + ly];
+            for (int i = lx; i < lx + x; ++i)
+                for (int j = ly; j < ly + y; ++j)
+                    if (plain[i * L + j] > max_h) max_h = plain[i * L + j];
+            if (new_h + z > max_h) max_h = new_h + z;
+            for (int i = lx; i < lx + x; ++i)
+                for (int j = ly; j < ly + y; ++j) plain[i * L + j] = max_h;
+            s->n_boxes += 1;
+            s->vol_sum += x * y * z;
+            /* bin3D.py:44-46,114,121: float64 (vol / binvol) * 10 */
+            reward = ((double)(item[0] * item[1] * item[2]) / binvol) * 10.0;
+            s->cursor += 1;                             /* bin3D.py:116-117 drop_box + generate_box_size */
+            done = 0;
+        } else {
+            reward = 0.0;                               /* bin3D.py:108-112 */
+            done = 1;
+        }
+        /* info: bin3D.py:111,123-125 ; get_ratio space.py:146-151 */
+        out->counter[e] = s->n_boxes;
+        out->ratio[e] = (double)s->vol_sum / binvol;
+        /* bench/monitor.py:58-64 */
+        s->ep_ret += reward;
+        s->ep_len += 1;
+        out->ep_ret[e] = s->ep_ret;
+        out->ep_len[e] = s->ep_len;
+        out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
+        out->done[e] = (uint8_t)done;
+        if (done) {                                     /* shmem_vec_env.py:128-129 */
+            s->episode += 1;
+            reset_bin(b, e, s);
+        }
+        next_box(b, e, s, item);
+        write_obs_mask(b, e, item, out);
+    }
+    return 0;
+}
+
+int bpp_mask_from_obs(const float *obs, float *mask, int32_t E, int32_t W, int32_t L, int32_t H,
+                      int32_t rotation, int32_t rule, void *stream) {
+    (void)stream;
+    if (!obs || !mask) return fail(BPP_E_BADARG, "bpp_mask_from_obs: NULL pointer");
+    if (E <= 0 || W <= 0 || L <= 0 || H <= 0) return fail(BPP_E_BADARG, "bpp_mask_from_obs: non-positive size");
+    if (rule != BPP_RULE_UTILS && rule != BPP_RULE_SPACE) return fail(BPP_E_BADARG, "bpp_mask_from_obs: bad rule");
+    int A = W * L, M = A * (1 + rotation);
+    int32_t plain[A];
+    for (int e = 0; e < E; ++e) {
+        const float *o = obs + (size_t)e * 4 * A;
+        for (int k = 0; k < A; ++k) plain[k] = (int32_t)o[k];
+        /* acktr/utils.py:43-45: int(box_info[k][0]) */
+        build_mask(rule, plain, W, L, H, (int)o[A], (int)o[2 * A], (int)o[3 * A], rotation, mask + (size_t)e * M);
+    }
+    return 0;
+}
+
+int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, int32_t E, int32_t W,
+                       int32_t L, int32_t H, int32_t rotation, int32_t rule, void *stream) {
+    (void)stream;
+    if (!hmap || !items || !mask) return fail(BPP_E_BADARG, "bpp_mask_from_hmap: NULL pointer");
+    if (E <= 0 || W <= 0 || L <= 0 || H <= 0) return fail(BPP_E_BADARG, "bpp_mask_from_hmap: non-positive size");
+    if (rule != BPP_RULE_UTILS && rule != BPP_RULE_SPACE) return fail(BPP_E_BADARG, "bpp_mask_from_hmap: bad rule");
+    int A = W * L, M = A * (1 + rotation);
+    for (int e = 0; e < E; ++e)
+        build_mask(rule, hmap + (size_t)e * A, W, L, H, items[3 * e], items[3 * e + 1], items[3 * e + 2], rotation,
+                   mask + (size_t)e * M);
+    return 0;
+}
+
+static uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
+                        uint64_t seed, uint64_t step, void *stream) {
+    (void)stream;
+    if (!mask || !actions) return fail(BPP_E_BADARG, "bpp_sample_feasible: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_sample_feasible: non-positive size");
+    for (int e = 0; e < E; ++e) {
+        const float *m = mask + (size_t)e * M;
+        int cnt = 0;
+        for (int k = 0; k < M; ++k) cnt += (m[k] != 0.0f);
+        if (cnt == 0) {
+            actions[e] = 0;
+            continue;
+        }
+        uint64_t pick = mix64(seed, (uint64_t)(env_id_base + e), step) % (uint64_t)cnt;
+        int64_t a = 0;
+        for (int k = 0; k < M; ++k)
+            if (m[k] != 0.0f) {
+                if (pick == 0) {
+                    a = k;
+                    break;
+                }
+                --pick;
+            }
+        actions[e] = a;
+    }
+    return 0;
+}

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of oracle/bpp_oracle.c (the CPU restatement of the
+reference environment step).  Imported by tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg, never by the product package.  numpy in, numpy out; no torch.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "bpp_oracle.c")
+LIB = os.path.join(HERE, "libbpp_oracle.so")
+HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
+
+RULE_UTILS, RULE_SPACE = 0, 1
+RESET_INIT, RESET_ADVANCE = 0, 1
+
+STATE_DTYPE = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),
+                        ("ep_ret", "<f8"), ("ep_len", "<i4"), ("reserved", "<i4")])
+assert STATE_DTYPE.itemsize == 32
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [("num_envs", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
+                ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
+                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+
+
+class StepOut(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+
+
+def build(force=False):
+    """gcc the restatement into oracle/libbpp_oracle.so (no-op when up to date)."""
+    if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
+            and os.path.getmtime(LIB) >= os.path.getmtime(HDR)):
+        return LIB
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", LIB, SRC])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = ctypes.CDLL(LIB)
+        L.bpp_last_error.restype = ctypes.c_char_p
+        L.bpp_reset.argtypes = [ctypes.POINTER(Batch), ctypes.c_int32, ctypes.POINTER(StepOut), ctypes.c_void_p]
+        L.bpp_step.argtypes = [ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.POINTER(StepOut), ctypes.c_void_p]
+        L.bpp_mask_from_obs.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
+        L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
+        L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("oracle error %d: %s" % (rc, lib().bpp_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleEnv(object):
+    """E bins stepped in lock-step on the host by the C restatement."""
+
+    def __init__(self, pool, size, rotation, num_envs, env_id_base=0, env_id_total=None, mask_rule=RULE_UTILS):
+        self.pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        assert self.pool.ndim == 3 and self.pool.shape[2] == 4
+        self.W, self.L, self.H = (int(v) for v in size)
+        self.A = self.W * self.L
+        self.rotation = int(bool(rotation))
+        self.M = self.A * (1 + self.rotation)
+        self.E = int(num_envs)
+        self.hmap = np.zeros((self.E, self.A), np.int32)
+        self.state = np.zeros(self.E, STATE_DTYPE)
+        self.out = dict(obs=np.zeros((self.E, 4 * self.A), np.float32), mask=np.zeros((self.E, self.M), np.float32),
+                        reward=np.zeros(self.E, np.float32), done=np.zeros(self.E, np.uint8),
+                        counter=np.zeros(self.E, np.int32), ratio=np.zeros(self.E, np.float64),
+                        ep_ret=np.zeros(self.E, np.float64), ep_len=np.zeros(self.E, np.int32))
+        self._b = Batch(self.E, self.W, self.L, self.H, self.rotation, int(mask_rule), self.pool.shape[0],
+                        self.pool.shape[1], int(env_id_base),
+                        int(env_id_total if env_id_total is not None else env_id_base + self.E),
+                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value)
+        self._o = StepOut(*[_p(self.out[k]).value for k in ("obs", "mask", "reward", "done", "counter", "ratio",
+                                                              "ep_ret", "ep_len")])
+        self._first = True
+
+    def reset(self):
+        _check(lib().bpp_reset(ctypes.byref(self._b), RESET_INIT if self._first else RESET_ADVANCE,
+                               ctypes.byref(self._o), None))
+        self._first = False
+        return self.out["obs"].copy(), self.out["mask"].copy()
+
+    def step(self, actions, copy=True):
+        a = np.ascontiguousarray(np.asarray(actions).reshape(-1), dtype=np.int64)
+        assert a.shape[0] == self.E
+        _check(lib().bpp_step(ctypes.byref(self._b), _p(a), ctypes.byref(self._o), None))
+        return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+
+def mask_from_obs(obs, size, rotation, rule=RULE_UTILS):
+    W, L, H = (int(v) for v in size)
+    obs = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1, 4 * W * L)
+    mask = np.zeros((obs.shape[0], W * L * (1 + int(bool(rotation)))), np.float32)
+    _check(lib().bpp_mask_from_obs(_p(obs), _p(mask), obs.shape[0], W, L, H, int(bool(rotation)), int(rule), None))
+    return mask
+
+
+def mask_from_hmap(hmap, items, size, rotation, rule=RULE_SPACE):
+    W, L, H = (int(v) for v in size)
+    hmap = np.ascontiguousarray(hmap, dtype=np.int32).reshape(-1, W * L)
+    items = np.ascontiguousarray(items, dtype=np.int32).reshape(-1, 3)
+    assert items.shape[0] == hmap.shape[0]
+    mask = np.zeros((hmap.shape[0], W * L * (1 + int(bool(rotation)))), np.float32)
+    _check(lib().bpp_mask_from_hmap(_p(hmap), _p(items), _p(mask), hmap.shape[0], W, L, H, int(bool(rotation)),
+                                    int(rule), None))
+    return mask
+
+
+def sample_feasible(mask, seed, step, env_id_base=0):
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    actions = np.zeros(mask.shape[0], np.int64)
+    _check(lib().bpp_sample_feasible(_p(mask), _p(actions), mask.shape[0], mask.shape[1], int(env_id_base),
+                                     int(seed), int(step), None))
+    return actions

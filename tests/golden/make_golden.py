@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE UNMODIFIED REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What is executed is the reference's own code, imported through oracle/ref_shims.py:
+  * envs.bpp0.PackingGame                       (envs/bpp0/bin3D.py)   one per bin
+  * baselines.bench.Monitor                     (baselines/bench/monitor.py)
+  * baselines.common.vec_env.DummyVecEnv        (auto-reset, float32 obs buffer; same VecEnv contract as
+                                                 the ShmemVecEnv main.py uses, acktr/envs.py:101-104)
+  * acktr.envs.VecNormalize(ob=False,ret=False) and acktr.envs.VecPyTorch  (acktr/envs.py:112-113)
+  * acktr.utils.get_possible_position / get_rotation_mask applied per observation row exactly as
+    main.py:122-129,163-169 does
+  * PackingGame.get_possible_position (rule "S", envs/bpp0/bin3D.py:72-93)
+Item sequences are injected with a replaying BoxCreator (ref_shims.make_replay_creator) so that the
+device env can be fed the same items.  Nothing in the fixtures is computed by this repository's code.
+
+Every array is stored in the narrowest integer type that holds it exactly (asserted), float values
+(rewards, ratios, episode returns) are stored as the reference's own float32/float64.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+from acktr.envs import VecNormalize, VecPyTorch  # noqa: E402
+from acktr.utils import get_possible_position, get_rotation_mask  # noqa: E402
+from baselines import bench  # noqa: E402
+from baselines.common.vec_env.dummy_vec_env import DummyVecEnv  # noqa: E402
+from envs.bpp0 import PackingGame  # noqa: E402
+from envs.bpp0.mdCreator import MDlayerBoxCreator  # noqa: E402
+
+
+def pad_pool(seqs, T, term):
+    """[P][T][4] uint8, (x,y,z,0), padded with the terminator; last entry always a terminator."""
+    P = len(seqs)
+    pool = np.zeros((P, T, 4), np.uint8)
+    pool[:, :, 0], pool[:, :, 1], pool[:, :, 2] = term
+    for p, s in enumerate(seqs):
+        assert len(s) <= T - 1, (len(s), T)
+        for t, it in enumerate(s):
+            pool[p, t, :3] = it
+    return pool
+
+
+def make_stack(pool, size, rotation, E):
+    term = tuple(int(v) for v in pool[0, -1, :3])
+    seqs = [[tuple(int(v) for v in it[:3]) for it in s] for s in pool]
+
+    def thunk(e):
+        def _t():
+            cr = ref_shims.make_replay_creator(seqs, term, env_id=e, env_total=E)
+            env = PackingGame(box_creator=cr, container_size=size, enable_rotation=rotation)
+            return bench.Monitor(env, None, allow_early_resets=False)
+        return _t
+
+    dummy = DummyVecEnv([thunk(e) for e in range(E)])
+    venv = VecPyTorch(VecNormalize(dummy, gamma=1.0, ob=False, ret=False), torch.device("cpu"))
+    return dummy, venv
+
+
+def loop_masks(obs, size, rotation):
+    """main.py:122-129 / :163-169 verbatim behaviour: one call per observation row."""
+    rows = []
+    for observation in obs:
+        if not rotation:
+            rows.append(get_possible_position(observation, size))
+        else:
+            rows.append(get_rotation_mask(observation, size))
+    return torch.FloatTensor(np.array(rows)).numpy()
+
+
+def space_masks(dummy):
+    return np.stack([m.env.get_possible_position().reshape(-1) for m in dummy.envs])
+
+
+def exact(a, dtype):
+    b = np.asarray(a).astype(dtype)
+    assert np.array_equal(b.astype(np.asarray(a).dtype), a), "lossy fixture cast"
+    return b
+
+
+def rollout_case(name, pool, size, rotation, E, steps, seed, p_random):
+    W, L, H = size
+    A = W * L
+    M = A * (1 + rotation)
+    dummy, venv = make_stack(pool, size, rotation, E)
+    rng = np.random.RandomState(seed)
+    obs = venv.reset()
+    mask = loop_masks(obs, size, rotation)
+    rec = dict(obs0=exact(obs.numpy(), np.uint8), mask0=exact(mask, np.uint8), smask0=exact(space_masks(dummy), np.uint8))
+    acts, obss, masks, smasks, rews, rews64, dones, counters, ratios, ep_r, ep_l, ep_r_raw = ([] for _ in range(12))
+    for _ in range(steps):
+        a = np.zeros(E, np.int64)
+        for e in range(E):
+            if rng.rand() < p_random:
+                a[e] = rng.randint(0, M + 2) - 1 if rng.rand() < 0.1 else rng.randint(0, M)
+                if not rotation:
+                    a[e] = min(max(a[e], -1), A)   # reference asserts for idx > A without rotation
+            else:
+                a[e] = rng.choice(np.flatnonzero(mask[e]))
+        obs, reward, done, infos = venv.step(torch.from_numpy(a).unsqueeze(1))
+        mask = loop_masks(obs, size, rotation)
+        acts.append(a)
+        obss.append(exact(obs.numpy(), np.uint8))
+        masks.append(exact(mask, np.uint8))
+        smasks.append(exact(space_masks(dummy), np.uint8))
+        assert reward.dtype == torch.float32 and tuple(reward.shape) == (E, 1)
+        rews.append(reward.numpy()[:, 0].copy())
+        dones.append(np.asarray(done).astype(np.uint8))
+        counters.append(np.array([i["counter"] for i in infos], np.int32))
+        ratios.append(np.array([float(i["ratio"]) for i in infos], np.float64))
+        ep_r.append(np.array([i["episode"]["r"] if "episode" in i else np.nan for i in infos], np.float64))
+        ep_l.append(np.array([i["episode"]["l"] if "episode" in i else -1 for i in infos], np.int32))
+        raw = np.full(E, np.nan, np.float64)
+        for e, i in enumerate(infos):
+            assert ("episode" in i) == bool(done[e])
+            if done[e]:
+                assert np.array_equal(i["mask"], np.ones(M))
+                raw[e] = dummy.envs[e].episode_rewards[-1]   # sum(self.rewards) before round(.,6)
+                assert round(raw[e], 6) == i["episode"]["r"]
+        ep_r_raw.append(raw)
+    rec.update(actions=np.stack(acts), obs=np.stack(obss), mask=np.stack(masks), smask=np.stack(smasks),
+               reward=np.stack(rews), done=np.stack(dones), counter=np.stack(counters), ratio=np.stack(ratios),
+               ep_r=np.stack(ep_r), ep_r_raw=np.stack(ep_r_raw), ep_l=np.stack(ep_l), pool=pool,
+               size=np.array(size, np.int32), rotation=np.int32(rotation))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    nd = int(rec["done"].sum())
+    print("%-22s E=%d steps=%d episodes=%d  mean mask density %.3f  -> %s (%d KB)" % (
+        name, E, steps, nd, rec["mask"].mean(), os.path.basename(path), os.path.getsize(path) // 1024))
+
+
+def cut2_reference_sequences(size, n, seed0):
+    """CUT-2 sequences from the reference generator itself (envs/bpp0/mdCreator.py:147-166) under
+    random.seed(seed0 + k); the stored trailing [10,10,10] (mdCreator.py:161) is dropped -- the pool's
+    pad terminator (W,L,H) takes its place."""
+    out = []
+    devnull = open(os.devnull, "w")
+    stdout = sys.stdout
+    sys.stdout = devnull
+    try:
+        cr = MDlayerBoxCreator(size, [2, 5])
+        for k in range(n):
+            random.seed(seed0 + k)
+            cr.reset()
+            out.append([tuple(b) for b in cr.box_set[:-1]])
+    finally:
+        sys.stdout = stdout
+    return out
+
+
+def mask_case(name, size, n, seed, lo, hi):
+    """Stand-alone mask vectors on random (not necessarily reachable) heightmaps."""
+    W, L, H = size
+    A = W * L
+    rng = np.random.RandomState(seed)
+    env = PackingGame(box_creator=ref_shims.make_replay_creator([[(1, 1, 1)]], (W, L, H)), container_size=size)
+    env.reset()
+    hmaps = np.zeros((n, A), np.int32)
+    items = np.zeros((n, 3), np.int32)
+    m_u = np.zeros((n, A), np.uint8)
+    m_ur = np.zeros((n, 2 * A), np.uint8)
+    m_s = np.zeros((n, A), np.uint8)
+    for k in range(n):
+        kind = k % 4
+        if kind == 0:      # plateaus: few distinct levels, feasible positions likely
+            h = np.zeros((W, L), np.int32)
+            for _ in range(rng.randint(0, 6)):
+                x0, y0 = rng.randint(0, W), rng.randint(0, L)
+                x1, y1 = rng.randint(x0, W) + 1, rng.randint(y0, L) + 1
+                h[x0:x1, y0:y1] = rng.randint(0, H + 1)
+        elif kind == 1:    # noise on 2 levels
+            h = rng.randint(0, 2, size=(W, L)).astype(np.int32) + rng.randint(0, H)
+        elif kind == 2:    # almost flat with a few dents/spikes
+            h = np.full((W, L), rng.randint(0, H), np.int32)
+            for _ in range(rng.randint(1, 4)):
+                h[rng.randint(0, W), rng.randint(0, L)] = rng.randint(0, H + 1)
+        else:              # uniform noise
+            h = rng.randint(0, H + 1, size=(W, L)).astype(np.int32)
+        it = (rng.randint(lo, hi + 1), rng.randint(lo, hi + 1), rng.randint(lo, hi + 1))
+        if k % 5 == 4:     # rules U and S diverge: >95% of a >=41-cell window on the max
+            x, y = 7, rng.randint(6, 8)  # level, but two of its corners dented
+            it = (x, y, rng.randint(1, 3))
+            lvl = rng.randint(1, H - 2)
+            h = np.full((W, L), lvl, np.int32)
+            i0, j0 = rng.randint(0, W - x + 1), rng.randint(0, L - y + 1)
+            cs = [(i0, j0), (i0 + x - 1, j0), (i0, j0 + y - 1), (i0 + x - 1, j0 + y - 1)]
+            for c in rng.permutation(4)[:2]:
+                h[cs[c]] = rng.randint(0, lvl)
+        if k % 17 == 0:
+            it = (W, L, H)            # the terminator item
+        if k % 23 == 0:
+            it = (W + 1, 2, 2)        # wider than the bin: empty candidate range -> all-ones
+        hmaps[k] = h.reshape(-1)
+        items[k] = it
+        obs = np.concatenate([h.reshape(-1), np.full(A, it[0]), np.full(A, it[1]), np.full(A, it[2])]).astype(np.float32)
+        m_u[k] = np.array(get_possible_position(obs, size), np.uint8)
+        m_ur[k] = exact(get_rotation_mask(torch.from_numpy(obs), size), np.uint8)
+        env.box_creator.box_list[0] = it
+        m_s[k] = exact(env.get_possible_position(plain=h).reshape(-1), np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, hmap=hmaps, items=items, mask_utils=m_u, mask_utils_rot=m_ur, mask_space=m_s,
+                        size=np.array(size, np.int32))
+    print("%-22s n=%d  U!=S rows: %d -> %s (%d KB)" % (name, n, int((m_u != m_s).any(1).sum()),
+                                                      os.path.basename(path), os.path.getsize(path) // 1024))
+
+
+def dataset_fixture():
+    """The reference's own CUT-2 item sequences for the 10x10x10 bin (dataset/cut_2.pt, 2100 python
+    lists of [x,y,z] each ending with a stored [10,10,10]) repacked as the pool format."""
+    d = torch.load(os.path.join(ref_shims.REFERENCE_ROOT, "dataset", "cut_2.pt"))
+    seqs = []
+    for s in d:
+        assert list(s[-1]) == [10, 10, 10]
+        seqs.append([tuple(it) for it in s[:-1]])
+    T = max(len(s) for s in seqs) + 1
+    pool = pad_pool(seqs, T, (10, 10, 10))
+    np.savez_compressed(os.path.join(HERE, "cut2_dataset_10.npz"), pool=pool)
+    print("cut2_dataset_10        P=%d T=%d" % pool.shape[:2])
+    return pool
+
+
+def main():
+    pool10 = dataset_fixture()
+    rollout_case("rollout_cut2_10", pool10[:96], (10, 10, 10), False, E=8, steps=320, seed=1, p_random=0.08)
+    rollout_case("rollout_cut2_10_rot", pool10[96:192], (10, 10, 10), True, E=8, steps=320, seed=2, p_random=0.08)
+    seq20 = cut2_reference_sequences((20, 20, 20), 12, seed0=100)
+    pool20 = pad_pool(seq20, max(len(s) for s in seq20) + 1, (20, 20, 20))
+    rollout_case("rollout_cut2_20", pool20, (20, 20, 20), False, E=4, steps=360, seed=3, p_random=0.03)
+    rng = np.random.RandomState(7)
+    rs = [[tuple(rng.randint(2, 6, size=3)) for _ in range(127)] for _ in range(24)]
+    rollout_case("rollout_rs_10", pad_pool(rs, 128, (10, 10, 10)), (10, 10, 10), False, E=6, steps=300, seed=4,
+                 p_random=0.05)
+    wide = [[tuple(rng.randint(1, 8, size=3)) for _ in range(95)] for _ in range(24)]
+    rollout_case("rollout_wide_8x12x9_rot", pad_pool(wide, 96, (8, 12, 9)), (8, 12, 9), True, E=6, steps=300, seed=5,
+                 p_random=0.05)
+    # short pool whose pad entry is a placeable item: cursors run past T and keep returning it
+    short = [[tuple(rng.randint(1, 4, size=3)) for _ in range(5)] for _ in range(3)]
+    rollout_case("rollout_short_5x4x6", pad_pool(short, 6, (2, 2, 1)), (5, 4, 6), True, E=5, steps=160, seed=6,
+                 p_random=0.1)
+    mask_case("masks_10", (10, 10, 10), 400, 11, 1, 7)
+    mask_case("masks_20", (20, 20, 20), 120, 12, 1, 9)
+    mask_case("masks_7x13x8", (7, 13, 8), 200, 13, 1, 8)
+
+
+if __name__ == "__main__":
+    main()
