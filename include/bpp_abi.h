@@ -52,7 +52,7 @@ typedef struct bpp_env_state {
     int32_t vol_sum;  /* sum of x*y*z over placed boxes, envs/bpp0/space.py:146-151                */
     double  ep_ret;   /* bench.Monitor running sum(self.rewards), baselines/bench/monitor.py:58-62 */
     int32_t ep_len;   /* bench.Monitor len(self.rewards), baselines/bench/monitor.py:63            */
-    int32_t reserved;
+    int32_t seq;      /* pool row this episode plays = (global bin id + episode*env_id_total) mod P */
 } bpp_env_state;
 
 /* One shard of bins living on one device.  Replaces N x (PackingGame + Space + BoxCreator +

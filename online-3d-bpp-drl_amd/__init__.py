@@ -1,0 +1,13 @@
+"""MI355X-native vectorised 3D bin-packing environment (hot path of alexfrom0815/Online-3D-BPP-DRL).
+
+Import as `bpp_amd` (the loader module at the repository root); the directory name itself is not a
+valid Python identifier."""
+from . import _lib, sequences  # noqa: F401
+from ._lib import build  # noqa: F401
+from .masks import (batched_mask_from_hmap, batched_mask_from_obs, get_possible_position,  # noqa: F401
+                    get_rotation_mask)
+from .spaces import Box, Discrete  # noqa: F401
+from .vec_env import BppVecEnv, LazyInfos, StepTensors  # noqa: F401
+
+__all__ = ["BppVecEnv", "LazyInfos", "StepTensors", "Box", "Discrete", "batched_mask_from_obs",
+           "batched_mask_from_hmap", "get_possible_position", "get_rotation_mask", "build", "sequences"]

@@ -1,0 +1,90 @@
+"""ctypes binding of libbpp_hip.so (include/bpp_abi.h) -- the only way the package reaches the kernels.
+
+There is deliberately NO fallback: if the HIP library cannot be built/loaded, or a call fails, a
+RuntimeError is raised.  The CPU oracle under oracle/ is never imported from here.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SRC = os.path.join(CSRC, "bpp_kernels.hip")
+LIB = os.path.join(CSRC, "libbpp_hip.so")
+HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
+
+ABI_VERSION = 1
+RULE_UTILS, RULE_SPACE = 0, 1
+RESET_INIT, RESET_ADVANCE = 0, 1
+
+SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
+           "bpp_mask_from_hmap", "bpp_sample_feasible"]
+
+
+class Batch(ctypes.Structure):
+    """struct bpp_batch"""
+    _fields_ = [("num_envs", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
+                ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
+                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+
+
+class StepOut(ctypes.Structure):
+    """struct bpp_step_out"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/bpp_kernels.hip for gfx950 into csrc/libbpp_hip.so (in-tree; no-op when fresh)."""
+    if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
+            and os.path.getmtime(LIB) >= os.path.getmtime(HDR)):
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError("libbpp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(expected at %s)" % LIB)
+        L = ctypes.CDLL(LIB)
+        L.bpp_abi_version.restype = ctypes.c_int
+        L.bpp_last_error.restype = ctypes.c_char_p
+        L.bpp_limits.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+        L.bpp_reset.argtypes = [ctypes.POINTER(Batch), ctypes.c_int32, ctypes.POINTER(StepOut), ctypes.c_void_p]
+        L.bpp_step.argtypes = [ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.POINTER(StepOut), ctypes.c_void_p]
+        L.bpp_mask_from_obs.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
+        L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
+        L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        if L.bpp_abi_version() != ABI_VERSION:
+            raise RuntimeError("libbpp_hip.so ABI version %d != %d" % (L.bpp_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libbpp_hip error %d: %s" % (rc, lib().bpp_last_error().decode()))
+
+
+def limits():
+    out = (ctypes.c_int32 * 2)()
+    check(lib().bpp_limits(out))
+    return int(out[0]), int(out[1])

@@ -1,0 +1,598 @@
+// bpp_kernels.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the vectorised 3D bin-packing
+// environment step (include/bpp_abi.h).  Hand-written for wave64; integer/indexing work, no MFMA.
+//
+// Work decomposition ("wave-autonomous bins"):
+//   * one 64-lane wavefront owns EPW consecutive bins (EPW = 16 for the 10x10 bin) for the whole
+//     step; waves never talk to each other, so there is no block-level barrier anywhere -- a
+//     256-thread workgroup is just 4 independent waves sharing an LDS allocation;
+//   * the wave's bins are contiguous in every tensor ([E][A] heightmap, [E][4A] observation,
+//     [E][M] mask), so each tensor chunk is streamed with full-width 16-byte-per-lane accesses
+//     (1 KiB per wave instruction), whatever the bin geometry;
+//   * the heightmap chunk is staged ONCE into LDS as bytes (heights <= H <= 255): EPW*A bytes per
+//     wave; placement check, heightmap update, observation and mask are all produced from that tile;
+//   * per-bin scalar work (action decode, placement rule, reward, Monitor accumulators, auto-reset,
+//     item fetch) runs lane-per-bin on the first EPW lanes; per-cell work runs lane-per-cell.
+//
+// Reference semantics are cited next to the code that restates them;
+// paths are relative to the reference root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bpp_abi.h"
+
+#pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxArea = 1024;  // W*L
+constexpr int kMaxDim = 255;    // W, L, H and item sizes are bytes
+
+enum Mode { kStep = 0, kResetInit = 1, kResetAdvance = 2, kMaskObs = 3, kMaskHmap = 4 };
+
+// n / d for n * d < 2^32 via one v_mul_hi_u32 (m = floor(2^32 / d) + 1).
+struct FastDiv {
+    uint32_t d, m;
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return __umulhi(n, m); }
+};
+FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, (uint32_t)((1ull << 32) / d) + 1u}; }
+
+struct Params {
+    // geometry
+    int32_t E, W, L, H, A, M, rotation, rule;
+    int32_t epw;           // bins per wave
+    int32_t lds_per_wave;  // bytes
+    int32_t off_mk, off_rec;
+    FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
+    // sequences
+    int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
+    double binvol;
+    const uint32_t *pool;  // [P][T] packed x | y<<8 | z<<16
+    // state
+    int32_t *hmap;
+    bpp_env_state *state;
+    const int64_t *actions;
+    // mask-only inputs
+    const float *obs_in;
+    const int32_t *hmap_in;
+    const int32_t *items_in;
+    // outputs
+    float *obs;
+    float *mask;
+    float *reward;
+    uint8_t *done;
+    int32_t *counter;
+    double *ratio;
+    double *ep_ret;
+    int32_t *ep_len;
+};
+
+// Per-bin record in LDS written by the bin's lane, read by the cell lanes.
+struct __attribute__((aligned(16))) BinRec {
+    uint32_t item;   // item shown in the next observation: x | y<<8 | z<<16
+    uint32_t place;  // lx | ly<<8 | x<<16 | y<<24 of the box just placed
+    uint32_t flags;  // bit0 placed, bit1 reset (zero the map), bits 8.. new top height
+    uint32_t any;    // set to 1 by any feasible candidate
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
+    // accesses across the point where other lanes' data is consumed.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// (max, #cells == max, #corners == max, #corners == corner-max) of window [lx,lx+x) x [ly,ly+y).
+// acktr/utils.py:14-16,23-26 and envs/bpp0/space.py:117-129.
+struct Win {
+    int mh, ma, c, sc;
+};
+__device__ __forceinline__ Win scan_window(const uint8_t *hm, int L, int lx, int ly, int x, int y) {
+    const uint8_t *p = hm + lx * L + ly;
+    int mh = 0, ma = 0;
+    for (int a = 0; a < x; ++a) {
+        const uint8_t *row = p + a * L;
+        for (int b = 0; b < y; ++b) {
+            int v = row[b];
+            ma = v > mh ? 1 : ma + (v == mh);
+            mh = v > mh ? v : mh;
+        }
+    }
+    int r00 = p[0], r10 = p[(x - 1) * L], r01 = p[y - 1], r11 = p[(x - 1) * L + y - 1];
+    int rm = max(max(r00, r10), max(r01, r11));
+    Win w;
+    w.mh = mh;
+    w.ma = ma;
+    w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
+    w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
+    return w;
+}
+
+// Integer form of the float64 tests `max_area/area > 0.95 / 0.85 / 0.50` (exhaustively
+// equal for 1 <= max_area <= area <= 1600; tests/test_threshold_rewrite.py re-proves it up to 1024*... ).
+// Rule U: acktr/utils.py:20-33.  Rule S (envs/bpp0/space.py:122-142) == rule U && sc >= 3, because when
+// the corner maximum rm equals max_h the two corner counts coincide and otherwise c == 0 in rule U.
+__device__ __forceinline__ bool feasible(const Win &w, int area, int z, int H, int rule) {
+    bool ok = (w.mh + z <= H) &&
+              ((20 * w.ma > 19 * area) || (w.c == 3 && 20 * w.ma > 17 * area) || (w.c == 4 && 2 * w.ma > area));
+    if (rule == BPP_RULE_SPACE) ok = ok && (w.sc >= 3);
+    return ok;
+}
+
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x >> 6;
+    const int e0 = (blockIdx.x * kWavesPerBlock + wid) * p.epw;
+    if (e0 >= p.E) return;  // no block-level barrier is ever used, a whole wave may leave
+    const int nenv = min(p.epw, p.E - e0);
+    const int A = p.A, L = p.L, M = p.M;
+    unsigned char *wb = smem + wid * p.lds_per_wave;
+    uint8_t *hm = wb;                        // [epw][A] heights
+    uint8_t *mk = wb + p.off_mk;             // [epw][M] feasibility bytes
+    BinRec *rec = (BinRec *)(wb + p.off_rec);  // [epw]
+    const int ncell = nenv * A;
+    constexpr int GW = VEC ? 4 : 1;          // cells handled per lane per access
+
+    // ---- phase 1: stage this wave's heightmaps into LDS as bytes -------------------------------
+    if (MODE == kStep || MODE == kMaskHmap) {
+        const int32_t *gh = (MODE == kStep ? p.hmap : p.hmap_in) + (size_t)e0 * A;
+        if (VEC) {
+            for (int q = lane; q < ncell / 4; q += kWave) {
+                int4 v = ((const int4 *)gh)[q];
+                ((uint32_t *)hm)[q] = (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24);
+            }
+        } else {
+            for (int c = lane; c < ncell; c += kWave) hm[c] = (uint8_t)gh[c];
+        }
+    } else if (MODE == kMaskObs) {
+        // acktr/utils.py:41-47: plane 0 of the observation row is the heightmap
+        if (VEC) {
+            for (int q = lane; q < ncell / 4; q += kWave) {
+                uint32_t el = p.divA4.div(q);  // bin within the wave (A/4 quads per bin)
+                float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * (A / 4)];
+                ((uint32_t *)hm)[q] = (uint32_t)(int)v.x | ((uint32_t)(int)v.y << 8) | ((uint32_t)(int)v.z << 16) |
+                                      ((uint32_t)(int)v.w << 24);
+            }
+        } else {
+            for (int c = lane; c < ncell; c += kWave) {
+                uint32_t el = p.divA.div(c);
+                hm[c] = (uint8_t)(int)p.obs_in[(size_t)(e0 + el) * 4 * A + (c - el * A)];
+            }
+        }
+    } else {
+        if (VEC) {
+            for (int q = lane; q < ncell / 4; q += kWave) ((uint32_t *)hm)[q] = 0u;  // space.py:22
+        } else {
+            for (int c = lane; c < ncell; c += kWave) hm[c] = 0;
+        }
+    }
+    wave_sync();
+
+    // ---- phase 2: lane-per-bin scalar work ------------------------------------------------------
+    if (lane < nenv) {
+        const int e = e0 + lane;
+        BinRec r;
+        r.place = 0;
+        r.flags = 0;
+        r.any = 0;
+        if (MODE == kStep) {
+            bpp_env_state st = p.state[e];
+            const int64_t act = p.actions[e];
+            // BoxCreator.preview(1)[0] (binCreator.py:15-18): current item, the one after it, and
+            // the first item of the next episode's sequence are fetched together.
+            const int T = p.T;
+            int seq_n = st.seq + p.seq_stride;
+            seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
+            const uint32_t *srow = p.pool + (size_t)st.seq * T;
+            const uint32_t it_cur = srow[min(st.cursor, T - 1)];
+            const uint32_t it_nxt = srow[min(st.cursor + 1, T - 1)];
+            const uint32_t it_rst = p.pool[(size_t)seq_n * T];
+            const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
+            // bin3D.py:96-105: rotated iff idx > area (strict)
+            int64_t idx = act;
+            const bool flag = p.rotation && idx > A;
+            if (flag) idx -= A;
+            const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
+            bool ok = idx >= 0 && idx < (int64_t)(p.W + 1) * L;
+            int lx = 0, ly = 0, top = 0;
+            if (ok) {
+                lx = (int)p.divL.div((uint32_t)idx);  // space.py:153-156
+                ly = (int)idx - lx * L;
+                ok = (lx + x <= p.W) && (ly + y <= L);  // space.py:112-115
+            }
+            if (ok) {
+                Win w = scan_window(hm + lane * A, L, lx, ly, x, y);
+                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);  // space.py:117-144
+                top = w.mh + z;                                   // space.py:42-45 with lz = max_h
+            }
+            const int vol = ix * iy * iz;
+            // bin3D.py:44-46,108-121: float64 (vol / binvol) * 10, 0.0 on failure
+            const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;
+            st.n_boxes += ok ? 1 : 0;
+            st.vol_sum += ok ? vol : 0;
+            st.ep_ret = st.ep_ret + rew;  // bench/monitor.py:58-62 (sum in step order)
+            st.ep_len += 1;
+            p.reward[e] = (float)rew;     // acktr/envs.py:192
+            p.done[e] = ok ? 0 : 1;
+            p.counter[e] = st.n_boxes;    // bin3D.py:111,124
+            p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
+            p.ep_ret[e] = st.ep_ret;
+            p.ep_len[e] = st.ep_len;
+            if (ok) {
+                st.cursor += 1;  // bin3D.py:116-117
+                r.item = it_nxt;
+                r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+                r.flags = 1u | ((uint32_t)top << 8);
+            } else {  // shmem_vec_env.py:128-129 auto-reset; bin3D.py:55-59
+                st.episode += 1;
+                st.seq = seq_n;
+                st.cursor = 0;
+                st.n_boxes = 0;
+                st.vol_sum = 0;
+                st.ep_ret = 0.0;
+                st.ep_len = 0;
+                r.item = it_rst;
+                r.flags = 2u;
+            }
+            p.state[e] = st;
+        } else if (MODE == kResetInit || MODE == kResetAdvance) {
+            bpp_env_state st;
+            if (MODE == kResetInit) {
+                st.episode = 0;
+                st.seq = (int32_t)(((uint32_t)p.base_mod + (uint32_t)e) % (uint32_t)p.P);
+            } else {
+                st = p.state[e];
+                st.episode += 1;
+                int s = st.seq + p.seq_stride;
+                st.seq = s >= p.P ? s - p.P : s;
+            }
+            st.cursor = 0;
+            st.n_boxes = 0;
+            st.vol_sum = 0;
+            st.ep_ret = 0.0;
+            st.ep_len = 0;
+            p.state[e] = st;
+            r.item = p.pool[(size_t)st.seq * p.T];
+            r.flags = 2u;
+        } else if (MODE == kMaskObs) {
+            // acktr/utils.py:43-45: x, y, z = int(plane[k][0])
+            const float *o = p.obs_in + (size_t)e * 4 * A;
+            r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
+        } else {
+            const int32_t *it = p.items_in + (size_t)e * 3;
+            r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
+        }
+        rec[lane] = r;
+    }
+    wave_sync();
+
+    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
+        // ---- phase 3a: apply the placement / reset to the LDS tile (space.py:36-46) -------------
+        if (MODE == kStep) {
+            for (int g = lane; g < ncell / GW; g += kWave) {
+                uint32_t packed = VEC ? ((uint32_t *)hm)[g] : (uint32_t)hm[g];
+                uint32_t outv = 0;
+#pragma unroll
+                for (int k = 0; k < GW; ++k) {
+                    const uint32_t c = g * GW + k;
+                    const uint32_t el = p.divA.div(c);
+                    const uint32_t cell = c - el * A;
+                    const uint32_t i = p.divL.div(cell), j = cell - i * L;
+                    const BinRec r = rec[el];
+                    uint32_t v = (packed >> (8 * k)) & 255u;
+                    const uint32_t lx = r.place & 255u, ly = (r.place >> 8) & 255u;
+                    const uint32_t x = (r.place >> 16) & 255u, y = r.place >> 24;
+                    if ((r.flags & 1u) && (i - lx) < x && (j - ly) < y) v = r.flags >> 8;
+                    if (r.flags & 2u) v = 0;
+                    outv |= v << (8 * k);
+                }
+                if (VEC) ((uint32_t *)hm)[g] = outv;
+                else hm[g] = (uint8_t)outv;
+            }
+            wave_sync();
+        }
+        // ---- phase 3b: stream out the int32 heightmap and the float32 observation ---------------
+        // bin3D.py:49-66: planes [hmap, x, y, z]; float32 at the VecEnv buffer (shmem_vec_env.py:42-43)
+        {
+            int32_t *gh = p.hmap + (size_t)e0 * A;
+            float *go = p.obs + (size_t)e0 * 4 * A;
+            const int per_plane = A / GW;
+            for (int g = lane; g < nenv * 4 * per_plane; g += kWave) {
+                const uint32_t pl = p.divA4.div(g);  // plane counter: bin*4 + plane
+                const uint32_t k = g - pl * per_plane;
+                const uint32_t el = pl >> 2, plane = pl & 3u;
+                if (plane == 0) {
+                    if (VEC) {
+                        const uint32_t v = ((uint32_t *)hm)[el * per_plane + k];
+                        const int4 iv = make_int4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
+                        ((int4 *)gh)[el * per_plane + k] = iv;
+                        ((float4 *)go)[g] = make_float4((float)iv.x, (float)iv.y, (float)iv.z, (float)iv.w);
+                    } else {
+                        const int v = hm[el * A + k];
+                        gh[el * A + k] = v;
+                        go[g] = (float)v;
+                    }
+                } else {
+                    const float f = (float)((rec[el].item >> (8 * (plane - 1))) & 255u);
+                    if (VEC) ((float4 *)go)[g] = make_float4(f, f, f, f);
+                    else go[g] = f;
+                }
+            }
+        }
+        if (p.mask == nullptr) return;
+    }
+
+    // ---- phase 4: feasibility of every candidate position (acktr/utils.py:37-94) ---------------
+    for (int c = lane; c < nenv * M; c += kWave) {
+        const uint32_t el = p.divM.div(c);
+        uint32_t r = c - el * M;
+        const bool rot = r >= (uint32_t)A;  // second half: item turned by 90 degrees, utils.py:81-89
+        if (rot) r -= A;
+        const uint32_t i = p.divL.div(r), j = r - i * L;
+        const uint32_t item = rec[el].item;
+        const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+        const int x = rot ? iy : ix, y = rot ? ix : iy;
+        bool f = false;
+        if ((int)i + x <= p.W && (int)j + y <= L) {  // utils.py:54-55 loop ranges
+            Win w = scan_window(hm + el * A, L, i, j, x, y);
+            f = feasible(w, x * y, z, p.H, p.rule);
+        }
+        mk[c] = f ? 1 : 0;
+        if (f) rec[el].any = 1u;
+    }
+    wave_sync();
+
+    // ---- phase 5: float32 mask out, all-ones when nothing is feasible (utils.py:59-60,91-92) ---
+    {
+        float *gm = p.mask + (size_t)e0 * M;
+        if (VEC) {
+            const int per = M / 4;
+            for (int g = lane; g < nenv * per; g += kWave) {
+                const uint32_t el = p.divA4.div(p.rotation ? (g >> 1) : g);  // g / (M/4)
+                const uint32_t v = rec[el].any ? ((uint32_t *)mk)[g] : 0x01010101u;
+                ((float4 *)gm)[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                (float)(v >> 24));
+            }
+        } else {
+            for (int c = lane; c < nenv * M; c += kWave) {
+                const uint32_t el = p.divM.div(c);
+                gm[c] = rec[el].any ? (float)mk[c] : 1.0f;
+            }
+        }
+    }
+}
+
+// Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// One wave per bin: lanes count set entries of their slice, an inclusive wave scan locates the
+// pick-th one.
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void sample_kernel(const float *mask, int64_t *actions, int E,
+                                                                        int M, int64_t env_id_base, uint64_t seed,
+                                                                        uint64_t step) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float *m = mask + (size_t)e * M;
+    const int per = (M + kWave - 1) / kWave;  // contiguous entries per lane
+    const int b = lane * per, en = min(b + per, M);
+    int cnt = 0;
+    for (int k = b; k < en; ++k) cnt += (m[k] != 0.0f);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        int o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, kWave - 1, kWave);
+    if (total == 0) {
+        if (lane == 0) actions[e] = 0;
+        return;
+    }
+    int pick = (int)(mix64(seed, (uint64_t)(env_id_base + e), step) % (uint64_t)total);
+    const int excl = incl - cnt;
+    if (pick >= excl && pick < incl) {
+        pick -= excl;
+        for (int k = b; k < en; ++k)
+            if (m[k] != 0.0f) {
+                if (pick == 0) {
+                    actions[e] = k;
+                    break;
+                }
+                --pick;
+            }
+    }
+}
+
+thread_local char g_err[256];
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+int check_geometry(int E, int W, int L, int H, int rotation, int rule) {
+    if (E <= 0 || W <= 0 || L <= 0 || H <= 0) return fail(BPP_E_BADARG, "non-positive size");
+    if (rotation != 0 && rotation != 1) return fail(BPP_E_BADARG, "rotation must be 0 or 1");
+    if (rule != BPP_RULE_UTILS && rule != BPP_RULE_SPACE) return fail(BPP_E_BADARG, "unknown mask rule");
+    if (W > kMaxDim || L > kMaxDim || H > kMaxDim || W * L > kMaxArea)
+        return fail(BPP_E_TOOLARGE, "bin too large: need W,L,H <= 255 and W*L <= 1024");
+    return 0;
+}
+
+// Geometry-dependent launch configuration.  EPW = bins per wave: as many as keep a 4-wave block's
+// LDS under ~32 KiB (>= 5 blocks = 20 waves per CU), at most 16.
+struct Launch {
+    Params p;
+    bool vec;
+    int blocks;
+    size_t lds;
+};
+
+Launch configure(int E, int W, int L, int H, int rotation, int rule) {
+    Launch l;
+    Params &p = l.p;
+    memset(&p, 0, sizeof p);
+    p.E = E;
+    p.W = W;
+    p.L = L;
+    p.H = H;
+    p.A = W * L;
+    p.rotation = rotation;
+    p.M = p.A * (1 + rotation);
+    p.rule = rule;
+    l.vec = (p.A % 4) == 0;
+    int epw = 16;
+    const char *env = getenv("BPP_EPW");
+    if (env && atoi(env) > 0) epw = atoi(env) > 64 ? 64 : atoi(env);
+    else
+        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16)) > 32 * 1024) epw >>= 1;
+    p.epw = epw;
+    p.off_mk = (epw * p.A + 15) & ~15;
+    p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
+    p.lds_per_wave = p.off_rec + epw * (int)sizeof(BinRec);
+    p.divL = make_fastdiv(L);
+    p.divA = make_fastdiv(p.A);
+    p.divM = make_fastdiv(p.M);
+    p.divA4 = make_fastdiv(l.vec ? p.A / 4 : p.A);
+    p.binvol = (double)W * (double)L * (double)H;
+    const int waves = (E + epw - 1) / epw;
+    l.blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    l.lds = (size_t)kWavesPerBlock * p.lds_per_wave;
+    return l;
+}
+
+template <int MODE>
+int launch(const Launch &l, hipStream_t s) {
+    if (l.vec)
+        hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+    else
+        hipLaunchKernelGGL((bpp_kernel<false, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need_all) {
+    if (!b->seq_pool || !b->hmap || !b->state) return fail(BPP_E_BADARG, "bpp_batch: NULL pointer");
+    if (b->pool_size <= 0 || b->pool_len <= 0) return fail(BPP_E_BADARG, "bpp_batch: empty pool");
+    if (b->env_id_base < 0 || b->env_id_total < b->env_id_base + b->num_envs)
+        return fail(BPP_E_BADARG, "bpp_batch: env_id_total < env_id_base + num_envs");
+    if (!out || !out->obs) return fail(BPP_E_BADARG, "bpp_step_out: NULL obs");
+    if (need_all && (!out->reward || !out->done || !out->counter || !out->ratio || !out->ep_ret || !out->ep_len))
+        return fail(BPP_E_BADARG, "bpp_step_out: NULL pointer");
+    if (!aligned16(b->hmap) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
+        ((uintptr_t)b->seq_pool & 3u))
+        return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
+    Params &p = l.p;
+    p.P = b->pool_size;
+    p.T = b->pool_len;
+    p.seq_stride = (int32_t)(b->env_id_total % b->pool_size);
+    p.base_mod = (int32_t)(b->env_id_base % b->pool_size);
+    p.pool = (const uint32_t *)b->seq_pool;
+    p.hmap = b->hmap;
+    p.state = b->state;
+    p.obs = out->obs;
+    p.mask = out->mask;
+    p.reward = out->reward;
+    p.done = out->done;
+    p.counter = out->counter;
+    p.ratio = out->ratio;
+    p.ep_ret = out->ep_ret;
+    p.ep_len = out->ep_len;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bpp_abi_version(void) { return BPP_ABI_VERSION; }
+
+const char *bpp_last_error(void) { return g_err; }
+
+int bpp_limits(int32_t out[2]) {
+    if (!out) return fail(BPP_E_BADARG, "bpp_limits: NULL");
+    out[0] = kMaxArea;
+    out[1] = kMaxDim;
+    return 0;
+}
+
+int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream) {
+    if (!b) return fail(BPP_E_BADARG, "bpp_reset: NULL batch");
+    if (mode != BPP_RESET_INIT && mode != BPP_RESET_ADVANCE) return fail(BPP_E_BADARG, "bpp_reset: bad mode");
+    int rc = check_geometry(b->num_envs, b->W, b->L, b->H, b->rotation, b->mask_rule);
+    if (rc) return rc;
+    Launch l = configure(b->num_envs, b->W, b->L, b->H, b->rotation, b->mask_rule);
+    rc = fill_batch(l, b, out, false);
+    if (rc) return rc;
+    return mode == BPP_RESET_INIT ? launch<kResetInit>(l, (hipStream_t)stream)
+                                  : launch<kResetAdvance>(l, (hipStream_t)stream);
+}
+
+int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *stream) {
+    if (!b || !actions) return fail(BPP_E_BADARG, "bpp_step: NULL pointer");
+    int rc = check_geometry(b->num_envs, b->W, b->L, b->H, b->rotation, b->mask_rule);
+    if (rc) return rc;
+    Launch l = configure(b->num_envs, b->W, b->L, b->H, b->rotation, b->mask_rule);
+    rc = fill_batch(l, b, out, true);
+    if (rc) return rc;
+    l.p.actions = actions;
+    return launch<kStep>(l, (hipStream_t)stream);
+}
+
+int bpp_mask_from_obs(const float *obs, float *mask, int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation,
+                      int32_t rule, void *stream) {
+    if (!obs || !mask) return fail(BPP_E_BADARG, "bpp_mask_from_obs: NULL pointer");
+    int rc = check_geometry(E, W, L, H, rotation, rule);
+    if (rc) return rc;
+    if (!aligned16(obs) || !aligned16(mask)) return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
+    Launch l = configure(E, W, L, H, rotation, rule);
+    l.p.obs_in = obs;
+    l.p.mask = mask;
+    return launch<kMaskObs>(l, (hipStream_t)stream);
+}
+
+int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, int32_t E, int32_t W, int32_t L,
+                       int32_t H, int32_t rotation, int32_t rule, void *stream) {
+    if (!hmap || !items || !mask) return fail(BPP_E_BADARG, "bpp_mask_from_hmap: NULL pointer");
+    int rc = check_geometry(E, W, L, H, rotation, rule);
+    if (rc) return rc;
+    if (!aligned16(hmap) || !aligned16(mask)) return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
+    Launch l = configure(E, W, L, H, rotation, rule);
+    l.p.hmap_in = hmap;
+    l.p.items_in = items;
+    l.p.mask = mask;
+    return launch<kMaskHmap>(l, (hipStream_t)stream);
+}
+
+int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed,
+                        uint64_t step, void *stream) {
+    if (!mask || !actions) return fail(BPP_E_BADARG, "bpp_sample_feasible: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_sample_feasible: non-positive size");
+    const int blocks = (E + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, mask, actions,
+                       E, M, env_id_base, seed, step);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+"""Drop-in replacements for the mask helpers the ACKTR loop calls per observation row
+(acktr/utils.py:37-94), plus batched device versions.  All of them run the HIP kernel
+`bpp_mask_from_obs` / `bpp_mask_from_hmap`; there is no host fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("mask kernels need a HIP device; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def batched_mask_from_obs(obs, container_size, enable_rotation=False, rule="utils", out=None):
+    """obs: [E, 4*W*L] (torch tensor or numpy; moved to the GPU if needed) -> float32 [E, M] device tensor.
+    Row e equals torch.FloatTensor(get_possible_position(obs[e], size)) (or get_rotation_mask)."""
+    W, L, H = (int(v) for v in container_size)
+    if not torch.is_tensor(obs):
+        obs = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32))
+    dev = obs.device if obs.device.type == "cuda" else _dev()
+    o = obs.reshape(-1, 4 * W * L).to(device=dev, dtype=torch.float32).contiguous()
+    E, M = o.shape[0], W * L * (1 + int(bool(enable_rotation)))
+    if out is None:
+        out = torch.empty((E, M), dtype=torch.float32, device=dev)
+    r = {"utils": _lib.RULE_UTILS, "space": _lib.RULE_SPACE}[rule]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().bpp_mask_from_obs(o.data_ptr(), out.data_ptr(), E, W, L, H, int(bool(enable_rotation)), r,
+                                                _stream(dev)))
+    return out
+
+
+def batched_mask_from_hmap(hmap, items, container_size, enable_rotation=False, rule="space", out=None):
+    """hmap int32 [E, W*L], items int32 [E,3] -> float32 [E, M]; rule='space', rotation off is
+    PackingGame.get_possible_position (envs/bpp0/bin3D.py:72-93) for every bin."""
+    W, L, H = (int(v) for v in container_size)
+    dev = hmap.device if torch.is_tensor(hmap) and hmap.device.type == "cuda" else _dev()
+    h = torch.as_tensor(hmap).reshape(-1, W * L).to(device=dev, dtype=torch.int32).contiguous()
+    it = torch.as_tensor(items).reshape(-1, 3).to(device=dev, dtype=torch.int32).contiguous()
+    if it.shape[0] != h.shape[0]:
+        raise ValueError("hmap and items disagree on the number of bins")
+    E, M = h.shape[0], W * L * (1 + int(bool(enable_rotation)))
+    if out is None:
+        out = torch.empty((E, M), dtype=torch.float32, device=dev)
+    r = {"utils": _lib.RULE_UTILS, "space": _lib.RULE_SPACE}[rule]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().bpp_mask_from_hmap(h.data_ptr(), it.data_ptr(), out.data_ptr(), E, W, L, H,
+                                                 int(bool(enable_rotation)), r, _stream(dev)))
+    return out
+
+
+def get_possible_position(observation, container_size):
+    """Same signature and return type as acktr.utils.get_possible_position (acktr/utils.py:37-62):
+    one observation row -> python list of W*L ints."""
+    m = batched_mask_from_obs(observation, container_size, False)
+    return m[0].to(torch.int32).cpu().numpy().reshape(-1).tolist()
+
+
+def get_rotation_mask(observation, container_size):
+    """Same as acktr.utils.get_rotation_mask (acktr/utils.py:64-94): int32 ndarray [2*W*L]."""
+    m = batched_mask_from_obs(observation, container_size, True)
+    return m[0].to(torch.int32).cpu().numpy().reshape(-1)

@@ -1,0 +1,122 @@
+"""Item-sequence pools fed to the device env (host side; the step kernels only index the pool).
+
+Pool format (include/bpp_abi.h): uint8 [P][T][4] = (x, y, z, 0); every row is padded with a terminator
+item and its LAST entry is always a terminator, which is what a cursor >= T keeps returning.
+
+Generators restate the reference's item creators.  They draw from a private `random.Random(seed)`,
+consuming it in exactly the reference's order, so under `random.seed(seed)` the reference creator
+produces the identical sequence (tests/test_sequences_vs_reference.py checks this in the build
+container).
+"""
+import random
+
+import numpy as np
+
+
+def pad_pool(seqs, terminator, T=None):
+    """List of item lists -> uint8 [P][T][4] padded with `terminator`."""
+    if T is None:
+        T = max(len(s) for s in seqs) + 1
+    term = tuple(int(v) for v in terminator)
+    pool = np.zeros((len(seqs), T, 4), np.uint8)
+    pool[:, :, 0], pool[:, :, 1], pool[:, :, 2] = term
+    for p, s in enumerate(seqs):
+        if len(s) > T - 1:
+            raise ValueError("sequence %d has %d items, pool rows hold %d + terminator" % (p, len(s), T - 1))
+        if len(s):
+            pool[p, :len(s), :3] = np.asarray(s, dtype=np.int64).reshape(-1, 3)
+    return pool
+
+
+def check_pool(pool, container_size):
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    if pool.ndim != 3 or pool.shape[2] != 4 or pool.shape[0] < 1 or pool.shape[1] < 1:
+        raise ValueError("pool must be uint8 [P][T][4]")
+    if (pool[:, :, :3] == 0).any():
+        raise ValueError("pool holds a zero-sized item")
+    return pool
+
+
+class _Cut(object):
+    """A cuboid being cut (identity semantics, like the reference's Box objects)."""
+    __slots__ = ("x", "y", "z", "low", "high")
+
+    def __init__(self, x, y, z, low, high):
+        self.x, self.y, self.z, self.low, self.high = x, y, z, low, high
+
+
+def cut2_sequence(container_size, bound, rng):
+    """One CUT-2 item sequence: cut the bin into boxes with every side in [bound[0], bound[1]], then
+    sort by the height of the box's base (stable).  Restates envs/bpp0/mdCreator.py:59-100
+    (Box.benchmark_split), :117-135 (bin.gen_benchmark, including its iterate-while-mutating list walk)
+    and :137-138 (depart_box).  Returns [(x, y, z), ...] without any terminator."""
+    lo, hi = bound
+    W, L, H = container_size
+    valid = []
+    invalid = [_Cut(W, L, H, 0, H)]
+    while True:
+        i = 0
+        while i < len(invalid):          # `for box in invalid_box` with remove/append inside
+            b = invalid[i]
+            i += 1
+            flags = []                   # mdCreator.py:60-66
+            if b.x > hi:
+                flags.append(0)
+            if b.y > hi:
+                flags.append(1)
+            if b.z > hi:
+                flags.append(2)
+            f = rng.choice(flags)        # :68
+            if f == 0:                   # :70-79
+                if b.x <= lo:
+                    continue
+                r = rng.randint(1, b.x)
+                if r < lo or b.x - r < lo:
+                    continue
+                subs = (_Cut(r, b.y, b.z, b.low, b.high), _Cut(b.x - r, b.y, b.z, b.low, b.high))
+            elif f == 1:                 # :80-89
+                if b.y < lo:
+                    continue
+                r = rng.randint(1, b.y)
+                if r < lo or b.y - r < lo:
+                    continue
+                subs = (_Cut(b.x, r, b.z, b.low, b.high), _Cut(b.x, b.y - r, b.z, b.low, b.high))
+            else:                        # :90-99
+                if b.z < lo:
+                    continue
+                r = rng.randint(1, b.z)
+                if r < lo or b.z - r < lo:
+                    continue
+                subs = (_Cut(b.x, b.y, b.z - r, b.low, b.high - r), _Cut(b.x, b.y, r, b.high - r, b.high))
+            # :124-130: the split box leaves the list (shifting the rest left under the iterator)
+            del invalid[i - 1]
+            for s in subs:
+                if lo <= s.x <= hi and lo <= s.y <= hi and lo <= s.z <= hi:
+                    valid.append(s)
+                else:
+                    invalid.append(s)
+        if not invalid:
+            break
+    valid.sort(key=lambda c: c.low)      # :137-138
+    return [(c.x, c.y, c.z) for c in valid]
+
+
+def cut2_pool(container_size, n, seed=0, bound=(2, 5), T=None):
+    """P = n CUT-2 sequences, sequence k drawn from random.Random(seed + k)."""
+    seqs = [cut2_sequence(container_size, bound, random.Random(seed + k)) for k in range(n)]
+    return pad_pool(seqs, container_size, T)
+
+
+def rs_pool(container_size, n, length, seed=0, box_set=None):
+    """RS sequences: items uniform over `box_set` (default {2..5}^3, acktr/arguments.py:122-128,
+    envs/bpp0/binCreator.py:24-40).  Distribution parity only (the reference draws from the global
+    numpy RNG one item at a time)."""
+    if box_set is None:
+        box_set = [(i, j, k) for i in range(2, 6) for j in range(2, 6) for k in range(2, 6)]
+    rng = np.random.RandomState(seed)
+    box_set = np.asarray(box_set, dtype=np.int64)
+    idx = rng.randint(0, len(box_set), size=(n, length))
+    pool = np.zeros((n, length + 1, 4), np.uint8)
+    pool[:, :length, :3] = box_set[idx]
+    pool[:, length, :3] = container_size
+    return pool

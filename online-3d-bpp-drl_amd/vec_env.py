@@ -1,0 +1,248 @@
+"""BppVecEnv -- the reference's VecEnv boundary re-presented over the HIP step kernels.
+
+Replaces `VecPyTorch(VecNormalize(ShmemVecEnv([PackingGame x N])))` as built by
+`acktr.envs.make_vec_envs` (acktr/envs.py:77-118): same attributes (`num_envs`, `observation_space`,
+`action_space`), same methods (`reset`, `step_async`, `step_wait`, `step`, `close`), same outputs
+(obs float32 [E,4A] on the device; reward float32 [E,1] CPU tensor; done numpy bool [E]; infos: one
+dict per bin with 'counter', 'ratio' and on terminal steps 'mask' and 'episode', bin3D.py:111,123-125,
+baselines/bench/monitor.py:64-75).  All bins live on ONE GPU and are stepped by one fused kernel launch.
+
+Tensor-native fast path (no host sync, everything stays on the device): `step_tensors(actions)`.
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .sequences import check_pool
+from .spaces import Box, Discrete
+
+
+class StepTensors(object):
+    """Device-resident result of one lock-step (views of the env's output buffers unless the env was
+    built with fresh_outputs=True)."""
+    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw[k])
+
+
+class LazyInfos(object):
+    """`infos` of a VecEnv step: behaves like the reference's tuple of E dicts, but the dicts are only
+    built when somebody indexes/iterates (one device->host copy for the whole batch on first use).
+    The ACKTR loop only reads `'episode' in infos[i]`, `infos[i]['episode']['r']`, `infos[i]['ratio']`
+    and `'bad_transition' in info` (main.py:159-162,173)."""
+
+    def __init__(self, env, res, t_now):
+        self._env = env
+        self._res = res
+        self._t = t_now
+        self._host = None
+        self._dicts = None
+
+    def _fetch(self):
+        if self._host is None:
+            r = self._res
+            self._host = dict(done=r.done.cpu().numpy().astype(bool), counter=r.counter.cpu().numpy(),
+                              ratio=r.ratio.cpu().numpy(), ep_ret=r.ep_ret.cpu().numpy(), ep_len=r.ep_len.cpu().numpy())
+        return self._host
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def _make(self, i):
+        h = self._fetch()
+        d = {"counter": int(h["counter"][i]), "ratio": np.float64(h["ratio"][i])}
+        if h["done"][i]:
+            d["mask"] = np.ones(shape=self._env.act_len)                       # bin3D.py:111
+            d["episode"] = {"r": round(float(h["ep_ret"][i]), 6), "l": int(h["ep_len"][i]),
+                            "t": round(self._t - self._env._tstart, 6)}        # bench/monitor.py:64
+        return d
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if self._dicts is None:
+            self._dicts = [None] * len(self)
+        if self._dicts[i] is None:
+            self._dicts[i] = self._make(i)
+        return self._dicts[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def done_indices(self):
+        return np.flatnonzero(self._fetch()["done"])
+
+
+class BppVecEnv(object):
+    """E independent bins stepped in lock-step on one MI355X.
+
+    pool:           uint8 [P][T][4] item sequences (sequences.py); episode k of global bin g plays row
+                    (g + k * env_id_total) mod P.
+    env_id_base/total: this shard's first global bin id / bins in the whole job (multi-GPU sharding).
+    mask_rule:      'utils' (acktr/utils.py check_box -- what the training loop consumes) or 'space'
+                    (Space.check_box, i.e. PackingGame.get_possible_position).
+    compute_mask:   also produce the feasibility mask of every returned observation (`location_masks`).
+    fresh_outputs:  allocate new output tensors every step (reference semantics: results of earlier
+                    steps stay valid); False = reuse one set of buffers, results are valid until the
+                    next step/reset call.
+    """
+
+    def __init__(self, num_envs, container_size=(10, 10, 10), enable_rotation=False, pool=None, device="cuda",
+                 env_id_base=0, env_id_total=None, mask_rule="utils", compute_mask=True, fresh_outputs=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BppVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BppVecEnv runs on a HIP device only, got %r" % (device,))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _lib.lib()
+        self.num_envs = self.E = int(num_envs)
+        self.bin_size = tuple(int(v) for v in container_size)
+        self.W, self.L, self.H = self.bin_size
+        self.area = self.A = self.W * self.L
+        self.can_rotate = bool(enable_rotation)
+        self.act_len = self.M = self.A * (1 + int(self.can_rotate))
+        self.obs_len = 4 * self.A
+        max_area, max_dim = _lib.limits()
+        if self.A > max_area or max(self.bin_size) > max_dim:
+            raise ValueError("bin %r exceeds kernel limits (W*L <= %d, sides <= %d)" % (self.bin_size, max_area, max_dim))
+        # bin3D.py:38-41
+        self.action_space = Discrete(self.act_len)
+        self.observation_space = Box(low=0.0, high=self.H, shape=(self.obs_len,))
+        if pool is None:
+            raise ValueError("an item-sequence pool is required (see sequences.cut2_pool / rs_pool)")
+        self.pool_host = check_pool(pool, self.bin_size)
+        self.mask_rule = {"utils": _lib.RULE_UTILS, "space": _lib.RULE_SPACE}[mask_rule]
+        self.compute_mask = bool(compute_mask)
+        self.fresh_outputs = bool(fresh_outputs)
+        self.env_id_base = int(env_id_base)
+        self.env_id_total = int(env_id_total) if env_id_total is not None else self.env_id_base + self.E
+        dev = self.device
+        with torch.cuda.device(dev):
+            self.pool = torch.from_numpy(self.pool_host).to(dev)
+            self.hmap = torch.zeros((self.E, self.A), dtype=torch.int32, device=dev)
+            self.state = torch.zeros((self.E, 8), dtype=torch.int32, device=dev)  # bpp_env_state[E], 32 B each
+        self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
+                                 self.pool_host.shape[0], self.pool_host.shape[1], self.env_id_base, self.env_id_total,
+                                 self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr())
+        self._bufs = None
+        self._out = None
+        self._res = None
+        self._first_reset = True
+        self._pending = None
+        self._tstart = time.time()
+        self.location_masks = None
+        self.closed = False
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        E, dev = self.E, self.device
+        b = dict(obs=torch.empty((E, self.obs_len), dtype=torch.float32, device=dev),
+                 mask=torch.empty((E, self.M), dtype=torch.float32, device=dev) if self.compute_mask else None,
+                 reward=torch.empty((E, 1), dtype=torch.float32, device=dev),
+                 done=torch.empty((E,), dtype=torch.uint8, device=dev),
+                 counter=torch.empty((E,), dtype=torch.int32, device=dev),
+                 ratio=torch.empty((E,), dtype=torch.float64, device=dev),
+                 ep_ret=torch.empty((E,), dtype=torch.float64, device=dev),
+                 ep_len=torch.empty((E,), dtype=torch.int32, device=dev))
+        out = _lib.StepOut(*[(b[k].data_ptr() if b[k] is not None else None)
+                             for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
+        return b, out
+
+    def _buffers(self):
+        if self.fresh_outputs or self._bufs is None:
+            self._bufs, self._out = self._alloc()
+        return self._bufs, self._out
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ VecEnv interface
+    def reset(self):
+        """All bins start a fresh episode (next sequence of their stride); returns obs [E,4A] float32."""
+        with torch.cuda.device(self.device):
+            bufs, out = self._buffers()
+            mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
+            _lib.check(self.lib.bpp_reset(ctypes.byref(self._batch), mode, ctypes.byref(out), self._stream()))
+        self._first_reset = False
+        self._tstart = time.time()
+        self.location_masks = bufs["mask"]
+        return bufs["obs"]
+
+    def step_tensors(self, actions):
+        """Enqueue one lock-step; returns device tensors, never synchronises.  actions: int64 [E] or [E,1]."""
+        if self._first_reset:
+            raise RuntimeError("call reset() before step()")
+        a = actions
+        if not torch.is_tensor(a):
+            a = torch.as_tensor(np.asarray(a))
+        a = a.reshape(-1)
+        if a.numel() != self.E:
+            raise ValueError("expected %d actions, got %d" % (self.E, a.numel()))
+        if a.device != self.device or a.dtype != torch.int64 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            bufs, out = self._buffers()
+            _lib.check(self.lib.bpp_step(ctypes.byref(self._batch), a.data_ptr(), ctypes.byref(out), self._stream()))
+        self.location_masks = bufs["mask"]
+        self._res = StepTensors(**bufs)
+        return self._res
+
+    def step_async(self, actions):
+        self._pending = self.step_tensors(actions)
+
+    def step_wait(self):
+        """(obs, reward, done, infos) with the reference's types (acktr/envs.py:189-193)."""
+        r, self._pending = self._pending, None
+        if r is None:
+            raise RuntimeError("step_wait() without step_async()")
+        infos = LazyInfos(self, r, time.time())
+        reward = r.reward.cpu()                     # CPU float32 [E,1], acktr/envs.py:192
+        done = infos._fetch()["done"]               # numpy bool [E]
+        return r.obs, reward, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.closed = True
+
+    # ------------------------------------------------------------------ extras
+    def sample_feasible(self, seed, step, mask=None, out=None):
+        """Uniform random feasible action per bin (bench/test action source), int64 [E] on the device."""
+        m = self.location_masks if mask is None else mask
+        if m is None:
+            raise RuntimeError("no mask available (compute_mask=False?)")
+        if out is None:
+            out = torch.empty((self.E,), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.bpp_sample_feasible(m.data_ptr(), out.data_ptr(), self.E, m.shape[1],
+                                                    self.env_id_base, int(seed), int(step), self._stream()))
+        return out
+
+    def state_dict(self):
+        """Env checkpoint (the reference never checkpoints env state; a handful of tensors here)."""
+        return {"hmap": self.hmap.clone(), "state": self.state.clone(), "first_reset": self._first_reset}
+
+    def load_state_dict(self, sd):
+        self.hmap.copy_(sd["hmap"])
+        self.state.copy_(sd["state"])
+        self._first_reset = bool(sd["first_reset"])
+
+    def state_numpy(self):
+        """bpp_env_state[E] as a structured numpy array (tests)."""
+        dt = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),
+                       ("ep_ret", "<f8"), ("ep_len", "<i4"), ("seq", "<i4")])
+        return self.state.cpu().numpy().view(dt).reshape(-1)

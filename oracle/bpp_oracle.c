@@ -165,7 +165,7 @@ static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
     s->vol_sum = 0;
     s->ep_ret = 0.0;
     s->ep_len = 0;
-    s->reserved = 0;
+    s->seq = (int32_t)((b->env_id_base + e + (int64_t)s->episode * b->env_id_total) % b->pool_size);
 }
 
 int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream) {

@@ -1,0 +1,184 @@
+"""Parity tests proper: the HIP path (through the C ABI, via bpp_amd) vs the reference's golden
+vectors and vs the oracle.  Everything is bit-exact: masks, heightmaps, observations, dones, counters
+(integer/index work) AND rewards/ratios/episode returns (float64 arithmetic in the reference's
+operation order; float32 only as the final cast), so every comparison is assert_array_equal."""
+import numpy as np
+import pytest
+
+from conftest import MASK_CASES, ROLLOUT_CASES, load_golden
+from test_oracle_golden import check_masks, check_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bpp():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bpp_amd
+    bpp_amd._lib.lib()
+    return bpp_amd
+
+
+class GpuEnv(object):
+    """numpy-in/numpy-out adapter so the golden replay helper can drive BppVecEnv."""
+
+    def __init__(self, bpp, pool, size, rot, E, rule, **kw):
+        self.env = bpp.BppVecEnv(E, size, enable_rotation=bool(rot), pool=pool,
+                                 mask_rule="space" if rule else "utils", **kw)
+
+    def reset(self):
+        obs = self.env.reset()
+        return obs.cpu().numpy(), self.env.location_masks.cpu().numpy()
+
+    def step(self, actions):
+        r = self.env.step_tensors(np.asarray(actions))
+        out = {k: getattr(r, k).cpu().numpy() for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len")}
+        out["reward"] = r.reward.cpu().numpy()[:, 0]
+        return out
+
+
+@pytest.mark.parametrize("case", ROLLOUT_CASES)
+def test_gpu_rollout_matches_reference_golden(bpp, case):
+    check_rollout(lambda pool, size, rot, E, rule: GpuEnv(bpp, pool, size, rot, E, rule), load_golden(case))
+
+
+@pytest.mark.parametrize("case", MASK_CASES)
+def test_gpu_masks_match_reference_golden(bpp, case):
+    rules = {0: "utils", 1: "space"}
+    check_masks(lambda obs, size, rot, rule: bpp.batched_mask_from_obs(obs, size, bool(rot), rules[rule]).cpu().numpy(),
+                lambda hm, it, size, rot, rule: bpp.batched_mask_from_hmap(hm, it, size, bool(rot), rules[rule]).cpu().numpy(),
+                load_golden(case))
+
+
+def test_gpu_dropin_mask_functions(bpp):
+    """acktr.utils-shaped single-row helpers: list[int] / int32 ndarray like the reference returns."""
+    g = load_golden("masks_10")
+    A = 100
+    k = 5
+    obs = np.concatenate([g["hmap"][k], np.full(A, g["items"][k, 0]), np.full(A, g["items"][k, 1]),
+                          np.full(A, g["items"][k, 2])]).astype(np.float32)
+    m = bpp.get_possible_position(obs, (10, 10, 10))
+    assert isinstance(m, list) and m == g["mask_utils"][k].tolist()
+    import torch
+    mr = bpp.get_rotation_mask(torch.from_numpy(obs), (10, 10, 10))
+    assert mr.dtype == np.int32 and np.array_equal(mr, g["mask_utils_rot"][k])
+
+
+GEOMS = [((10, 10, 10), False, 1024, 11), ((10, 10, 10), True, 1000, 12), ((20, 20, 20), False, 160, 13),
+         ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16)]
+
+
+@pytest.mark.parametrize("size,rot,E,seed", GEOMS)
+def test_gpu_vs_oracle_random_rollout(bpp, oracle, size, rot, E, seed):
+    """Longer seeded rollouts on many bins (incl. bin counts that are not a multiple of the per-wave
+    group and non-multiple-of-4 areas): device sampler == oracle sampler, all outputs and the final
+    state bit-exact."""
+    rng = np.random.RandomState(seed)
+    lo, hi = 1, max(2, min(size) // 2)
+    seqs = [[tuple(rng.randint(lo, hi + 1, size=3)) for _ in range(rng.randint(3, 60))] for _ in range(37)]
+    pool = bpp.sequences.pad_pool(seqs, size)
+    for rule in ("utils", "space"):
+        env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, mask_rule=rule, env_id_base=5, env_id_total=E + 9)
+        ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=5, env_id_total=E + 9,
+                               mask_rule=1 if rule == "space" else 0)
+        obs = env.reset()
+        robs, rmask = ref.reset()
+        np.testing.assert_array_equal(obs.cpu().numpy(), robs)
+        np.testing.assert_array_equal(env.location_masks.cpu().numpy(), rmask)
+        M = env.act_len
+        for t in range(60):
+            a = env.sample_feasible(seed=seed, step=t).cpu().numpy()
+            np.testing.assert_array_equal(a, oracle.sample_feasible(rmask, seed, t, env_id_base=5))
+            bad = rng.rand(E) < 0.05
+            a[bad] = rng.randint(-2, M + 3, size=int(bad.sum()))
+            r = env.step_tensors(a)
+            o = ref.step(a)
+            for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg="%s t=%d" % (k, t))
+            np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
+            rmask = o["mask"]
+            if t == 30:   # VecEnv.reset() mid-run: every bin moves on to its next sequence
+                np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset()[0])
+                rmask = ref.out["mask"].copy()
+                np.testing.assert_array_equal(env.location_masks.cpu().numpy(), rmask)
+        np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+        st = env.state_numpy()
+        for f in ("cursor", "episode", "n_boxes", "vol_sum", "ep_ret", "ep_len", "seq"):
+            np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
+
+
+def test_gpu_reward_table_all_volumes(bpp, oracle):
+    """float32(float64(vol/binvol)*10) for every reachable volume of the 10^3 and 20^3 item sets."""
+    for size in ((10, 10, 10), (20, 20, 20)):
+        items = [(x, y, z) for x in range(1, 8) for y in range(1, 8) for z in range(1, 8)]
+        pool = bpp.sequences.pad_pool([[it] for it in items], size)
+        E = len(items)
+        env = bpp.BppVecEnv(E, size, pool=pool)
+        ref = oracle.OracleEnv(pool, size, False, E)
+        env.reset(), ref.reset()
+        r = env.step_tensors(np.zeros(E, np.int64))
+        o = ref.step(np.zeros(E, np.int64))
+        np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
+        np.testing.assert_array_equal(r.ratio.cpu().numpy(), o["ratio"])
+        binvol = float(np.prod(size))
+        expect = np.array([np.float32(np.float64(x * y * z / binvol) * 10) for x, y, z in items], np.float32)
+        np.testing.assert_array_equal(o["reward"], expect)
+
+
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 65536), ((10, 10, 10), True, 65536),
+                                         ((20, 20, 20), False, 32768)])
+def test_gpu_full_size_properties_and_slices(bpp, oracle, size, rot, E):
+    """BASELINE.json's full sizes: size-independent invariants on ALL bins plus bit-exact oracle
+    replays of three 192-bin slices (bins are independent and sequences are keyed by global bin id,
+    so a slice can be replayed in isolation with env_id_base/env_id_total)."""
+    import torch
+    W, L, H = size
+    A = W * L
+    pool = bpp.sequences.cut2_pool(size, 64 if A > 100 else 512, seed=1)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool)
+    slices = [0, E // 2 - 96, E - 192]
+    refs = [oracle.OracleEnv(pool, size, rot, 192, env_id_base=s, env_id_total=E) for s in slices]
+    obs = env.reset()
+    for ref, s in zip(refs, slices):
+        robs, rmask = ref.reset()
+        np.testing.assert_array_equal(obs[s:s + 192].cpu().numpy(), robs)
+        np.testing.assert_array_equal(env.location_masks[s:s + 192].cpu().numpy(), rmask)
+    ret_sum = torch.zeros(E, dtype=torch.float64, device=obs.device)
+    n_done = 0
+    for t in range(24):
+        a = env.sample_feasible(seed=9, step=t)
+        if t % 5 == 4:
+            a[::3] = A - 1      # mostly infeasible corner placements
+        prev_mask = env.location_masks.clone()
+        r = env.step_tensors(a)
+        for ref, s in zip(refs, slices):
+            o = ref.step(a[s:s + 192].cpu().numpy())
+            for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(getattr(r, k)[s:s + 192].cpu().numpy(), o[k], err_msg="%s t=%d" % (k, t))
+            np.testing.assert_array_equal(r.reward[s:s + 192, 0].cpu().numpy(), o["reward"])
+        done = r.done.bool()
+        o4 = r.obs.view(E, 4, A)
+        # plane 0 is the int32 heightmap, planes 1-3 are constant = next item
+        assert torch.equal(o4[:, 0], env.hmap.float())
+        assert bool((o4[:, 1:] == o4[:, 1:, :1]).all())
+        assert int(env.hmap.max()) <= H and int(env.hmap.min()) >= 0
+        # masks are 0/1, never all-zero
+        assert bool(((r.mask == 0) | (r.mask == 1)).all()) and bool((r.mask.sum(1) > 0).all())
+        # a finished bin shows an empty map; reward is 0 exactly on terminal steps (items have volume)
+        assert bool((env.hmap[done] == 0).all())
+        assert torch.equal(r.reward[:, 0] == 0, done)
+        # the action taken was feasible under rule U for everything we did not overwrite; rule U and
+        # rule S coincide for items <= 5x5 so those steps cannot terminate unless the
+        # mask was the all-ones fallback
+        if t % 5 != 4:
+            fallback = prev_mask.sum(1) == prev_mask.shape[1]
+            assert bool((~done | fallback).all())
+        # Monitor: episode return == sum of rewards; == 10 * final ratio up to float64 rounding
+        ret_sum += r.reward[:, 0].double()
+        if bool(done.any()):
+            assert torch.allclose(r.ep_ret[done], 10.0 * r.ratio[done], rtol=0, atol=1e-9)
+            assert torch.allclose(r.ep_ret[done], ret_sum[done], rtol=0, atol=1e-5)  # float32 rewards summed
+            n_done += int(done.sum())
+        ret_sum[done] = 0
+    assert n_done > 0

@@ -1,0 +1,90 @@
+"""Host-side logic that needs no GPU: sequence pools, spaces, lazy infos, threshold rewrite."""
+import random
+
+import numpy as np
+import pytest
+
+import bpp_amd
+from bpp_amd import sequences
+from bpp_amd.vec_env import LazyInfos
+from conftest import load_golden
+
+
+def test_threshold_integer_rewrite_is_exact():
+    """The kernels test 20*ma > 19*area etc. instead of ma/area > 0.95 (float64): identical for every
+    window the kernels accept (area <= 1024)."""
+    ma, area = np.meshgrid(np.arange(1, 1025), np.arange(1, 1025))
+    keep = ma <= area
+    ma, area = ma[keep].astype(np.int64), area[keep].astype(np.int64)
+    r = ma / area
+    assert np.array_equal(r > 0.95, 20 * ma > 19 * area)
+    assert np.array_equal(r > 0.85, 20 * ma > 17 * area)
+    assert np.array_equal(r > 0.50, 2 * ma > area)
+
+
+def test_cut2_sequences_are_exact_partitions():
+    for size in ((10, 10, 10), (20, 20, 20), (8, 12, 10)):
+        for s in range(5):
+            seq = sequences.cut2_sequence(size, (2, 5), random.Random(s))
+            assert sum(x * y * z for x, y, z in seq) == size[0] * size[1] * size[2]
+            assert all(2 <= v <= 5 for it in seq for v in it)
+
+
+def test_cut2_generator_reproduces_reference_dataset_statistics():
+    """Same length/size distribution family as the reference's dataset/cut_2.pt (2100 sequences)."""
+    ds = load_golden("cut2_dataset_10")["pool"]
+    n_ds = (ds[:, :, 0] != 10).sum(1)
+    mine = sequences.cut2_pool((10, 10, 10), 400, seed=123)
+    n_me = (mine[:, :, 0] != 10).sum(1)
+    assert abs(n_ds.mean() - n_me.mean()) < 1.5 and n_me.min() >= 8 and n_me.max() <= 60
+    vols = (mine[:, :, :3].astype(np.int64).prod(2) * (mine[:, :, 0] != 10)).sum(1)
+    assert (vols == 1000).all()
+
+
+def test_pool_format():
+    pool = sequences.pad_pool([[(2, 3, 4)], [(1, 1, 1), (2, 2, 2)]], (10, 10, 10))
+    assert pool.shape == (2, 3, 4) and pool.dtype == np.uint8
+    assert pool[0, 1].tolist() == [10, 10, 10, 0] and pool[1, 2].tolist() == [10, 10, 10, 0]
+    with pytest.raises(ValueError):
+        sequences.check_pool(np.zeros((2, 3, 4), np.uint8), (10, 10, 10))
+    rs = sequences.rs_pool((10, 10, 10), 8, 130, seed=1)
+    assert rs.shape == (8, 131, 4) and rs[:, :130, :3].min() >= 2 and rs[:, :130, :3].max() <= 5
+
+
+def test_spaces_look_like_gym():
+    d = bpp_amd.Discrete(200)
+    assert d.__class__.__name__ == "Discrete" and d.n == 200 and d.shape == ()
+    b = bpp_amd.Box(0.0, 10, (400,))
+    assert b.shape == (400,) and b.dtype == np.float32 and b.high.max() == 10
+
+
+class _FakeTensor(object):
+    def __init__(self, a):
+        self.a = a
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self.a
+
+
+def test_lazy_infos_match_reference_dict_shape():
+    class Env:
+        num_envs, act_len, _tstart = 3, 100, 0.0
+
+    class Res:
+        done = _FakeTensor(np.array([0, 1, 0], np.uint8))
+        counter = _FakeTensor(np.array([3, 11, 0], np.int32))
+        ratio = _FakeTensor(np.array([0.1, 0.476, 0.0]))
+        ep_ret = _FakeTensor(np.array([1.0, 4.7600000000000001, 0.0]))
+        ep_len = _FakeTensor(np.array([3, 12, 1], np.int32))
+
+    infos = LazyInfos(Env(), Res(), 5.0)
+    assert len(infos) == 3 and sorted(infos[0].keys()) == ["counter", "ratio"]
+    t = infos[1]
+    assert sorted(t.keys()) == ["counter", "episode", "mask", "ratio"]
+    assert t["episode"] == {"r": 4.76, "l": 12, "t": 5.0} and t["mask"].shape == (100,) and t["counter"] == 11
+    assert ["episode" in i for i in infos] == [False, True, False]
+    assert infos.done_indices().tolist() == [1]
+    assert infos[-1]["counter"] == 0
