@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/s of the fused HIP environment step (BASELINE.json config[1]).
+
+One "step" = one lock-step of all bins on this rank: device-side uniform-random-feasible action
+sampling (bpp_sample_feasible) + the fused step kernel (bpp_step: action decode, placement rule,
+heightmap update, reward, Monitor accumulators, auto-reset, next observation, feasibility mask) +
+the episode-statistics accumulator.  Inputs (pool, state, previous mask) are resident in HBM.
+
+    python bench.py --gpus 1 --steps 200 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job env steps/s, plus
+`roofline` (dominant kernel = bpp_step; algorithmic bytes / HIP-event-measured launch duration vs the
+8 TB/s HBM peak) and `cpu_baseline` (the C oracle, a scalar port of the reference, timed on this box's
+host: 1 core, bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def algorithmic_bytes_per_env_step(A, M):
+    """contract-mandated I/O of one env step -- int32 heightmap read + write (4A + 4A),
+    float32 observation write (16A), float32 mask write (4M), 64 B of per-bin scalars (action, reward,
+    done, item, state/accumulators)."""
+    return 4 * A + 4 * A + 16 * A + 4 * M + 64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=65536, help="bins per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, nargs=3, default=[10, 10, 10])
+    ap.add_argument("--rotation", action="store_true")
+    ap.add_argument("--pool", type=int, default=8192, help="CUT-2 sequences in the pool")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pool, size, rotation, seconds):
+    """The oracle (oracle/bpp_oracle.c: scalar C port of the reference step + mask) on ONE host core,
+    same workload and policy, bounded sample.  Checker/baseline only -- never the product path."""
+    from oracle import oracle as orc
+    orc.build()
+    E = 256
+    env = orc.OracleEnv(pool, size, rotation, E, env_id_base=0, env_id_total=E)
+    _, mask = env.reset()
+
+    def run(n, t_base):
+        nonlocal mask
+        t0 = time.perf_counter()
+        for t in range(n):
+            a = orc.sample_feasible(mask, 1, t_base + t)
+            mask = env.step(a, copy=False)["mask"]
+        return time.perf_counter() - t0
+
+    probe = 40
+    dt = run(probe, 0)
+    n = max(probe, int(seconds / max(dt / probe, 1e-9)))
+    dt = run(n, probe)
+    return {"value": E * n / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask), "
+                      "%d bins x %d lock-steps, %.1f s, same CUT-2 pool and uniform-feasible policy" % (E, n, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import bpp_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    size = tuple(args.size)
+    A = size[0] * size[1]
+    M = A * (2 if args.rotation else 1)
+    E = args.envs
+    pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)       # identical on every rank
+    env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=pool, device=device,
+                            env_id_base=rank * E, env_id_total=world * E)
+    stats = bpp_amd.EpisodeStats(device)
+    actions = torch.empty(E, dtype=torch.int64, device=device)
+    env.reset()
+
+    def lockstep(t):
+        env.sample_feasible(seed=1, step=t, out=actions)
+        res = env.step_tensors(actions)
+        stats.update(res)
+        return res
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for t in range(args.warmup):
+        lockstep(t)
+    stats.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        lockstep(args.warmup + t)
+    stats.all_reduce()          # the only collective of the path: 32 bytes, once per logging interval
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    summary = stats.summary()
+
+    # dominant kernel (bpp_step) launch duration, HIP events on the launch stream, after the timed region
+    n_ev = min(args.steps, 200)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for t, (e0, e1) in enumerate(evs):
+        env.sample_feasible(seed=1, step=args.warmup + args.steps + t, out=actions)
+        e0.record()
+        env.step_tensors(actions)
+        e1.record()
+    torch.cuda.synchronize(device)
+    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if rank == 0:
+        b_alg = algorithmic_bytes_per_env_step(A, M)
+        achieved = b_alg * E / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%dx%dx%d_rot%d_E%d" % (size + (int(args.rotation), E)))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (whole node), 10^3 bin, 65536 envs; bit-exact mask vs ref",
+            "value": world * E * args.steps / dt,
+            "unit": "env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
+                                   % (size + (" + rotation" if args.rotation else "", E)),
+                       "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": args.pool,
+                       "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only" % world,
+                       "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
+                       "mean_episode_length": round(summary["mean_length"], 2)},
+            "roofline": {"bound": "hbm", "kernel": "bpp_kernel<VEC,kStep> (bpp_step)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
+                         "launch_us_min": kern_ms[0] * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

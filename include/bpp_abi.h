@@ -123,6 +123,14 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
                         uint64_t seed, uint64_t step, void *stream);
 
+/* Device-side replacement of the training loop's per-bin `infos` scan (main.py:159-162: for every
+ * finished episode append info['episode']['r'] and info['ratio'] to the logging deques):
+ * acc[0] += sum of episode returns, acc[1] += sum of final ratios, acc[2] += sum of episode lengths,
+ * acc[3] += number of episodes, over bins with done != 0.  acc: double[4], caller-zeroed; it is the
+ * 32-byte record that multi-GPU jobs all-reduce.  Summation order is unspecified. */
+int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
+                      int32_t E, double *acc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

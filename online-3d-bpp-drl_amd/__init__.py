@@ -7,7 +7,8 @@ from ._lib import build  # noqa: F401
 from .masks import (batched_mask_from_hmap, batched_mask_from_obs, get_possible_position,  # noqa: F401
                     get_rotation_mask)
 from .spaces import Box, Discrete  # noqa: F401
+from .stats import EpisodeStats, shard_range  # noqa: F401
 from .vec_env import BppVecEnv, LazyInfos, StepTensors  # noqa: F401
 
 __all__ = ["BppVecEnv", "LazyInfos", "StepTensors", "Box", "Discrete", "batched_mask_from_obs",
-           "batched_mask_from_hmap", "get_possible_position", "get_rotation_mask", "build", "sequences"]
+           "batched_mask_from_hmap", "get_possible_position", "get_rotation_mask", "build", "sequences", "EpisodeStats", "shard_range"]

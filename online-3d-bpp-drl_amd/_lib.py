@@ -18,7 +18,7 @@ RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
-           "bpp_mask_from_hmap", "bpp_sample_feasible"]
+           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats"]
 
 
 class Batch(ctypes.Structure):
@@ -73,6 +73,7 @@ def lib():
         L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
         L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         if L.bpp_abi_version() != ABI_VERSION:
             raise RuntimeError("libbpp_hip.so ABI version %d != %d" % (L.bpp_abi_version(), ABI_VERSION))
         _lib = L

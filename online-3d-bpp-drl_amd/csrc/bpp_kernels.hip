@@ -416,6 +416,33 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sample_kernel(const fl
     }
 }
 
+// Episode statistics of the finished bins (main.py:159-162): per-lane partial sums, wave shuffle
+// reduction, one float64 atomic per wave and statistic.
+__global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
+                                                    const int32_t *ep_len, int E, double *acc) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
+        if (done[e]) {
+            s0 += ep_ret[e];
+            s1 += ratio[e];
+            s2 += (double)ep_len[e];
+            s3 += 1.0;
+        }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        s0 += __shfl_down(s0, d, kWave);
+        s1 += __shfl_down(s1, d, kWave);
+        s2 += __shfl_down(s2, d, kWave);
+        s3 += __shfl_down(s3, d, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && s3 != 0.0) {
+        atomicAdd(acc + 0, s0);
+        atomicAdd(acc + 1, s1);
+        atomicAdd(acc + 2, s2);
+        atomicAdd(acc + 3, s3);
+    }
+}
+
 thread_local char g_err[256];
 
 int fail(int code, const char *msg) {
@@ -591,6 +618,16 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
     const int blocks = (E + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, mask, actions,
                        E, M, env_id_base, seed, step);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len, int32_t E,
+                      double *acc, void *stream) {
+    if (!done || !ep_ret || !ratio || !ep_len || !acc) return fail(BPP_E_BADARG, "bpp_episode_stats: NULL pointer");
+    if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_stats: non-positive size");
+    const int blocks = (E + 1023) / 1024 < 256 ? (E + 1023) / 1024 : 256;
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, E, acc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }

@@ -324,3 +324,18 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
     }
     return 0;
 }
+
+int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
+                      int32_t E, double *acc, void *stream) {
+    (void)stream;
+    if (!done || !ep_ret || !ratio || !ep_len || !acc) return fail(BPP_E_BADARG, "bpp_episode_stats: NULL pointer");
+    if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_stats: non-positive size");
+    for (int e = 0; e < E; ++e)
+        if (done[e]) {                                  /* main.py:159-162 */
+            acc[0] += ep_ret[e];
+            acc[1] += ratio[e];
+            acc[2] += (double)ep_len[e];
+            acc[3] += 1.0;
+        }
+    return 0;
+}

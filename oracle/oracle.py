@@ -57,6 +57,7 @@ def lib():
         L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
         L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -133,3 +134,14 @@ def sample_feasible(mask, seed, step, env_id_base=0):
     _check(lib().bpp_sample_feasible(_p(mask), _p(actions), mask.shape[0], mask.shape[1], int(env_id_base),
                                      int(seed), int(step), None))
     return actions
+
+
+def episode_stats(done, ep_ret, ratio, ep_len, acc=None):
+    done = np.ascontiguousarray(done, dtype=np.uint8)
+    ep_ret = np.ascontiguousarray(ep_ret, dtype=np.float64)
+    ratio = np.ascontiguousarray(ratio, dtype=np.float64)
+    ep_len = np.ascontiguousarray(ep_len, dtype=np.int32)
+    if acc is None:
+        acc = np.zeros(4, np.float64)
+    _check(lib().bpp_episode_stats(_p(done), _p(ep_ret), _p(ratio), _p(ep_len), done.shape[0], _p(acc), None))
+    return acc
