@@ -46,7 +46,7 @@ struct Params {
     int32_t E, W, L, H, A, M, rotation, rule;
     int32_t epw;           // bins per wave
     int32_t lds_per_wave;  // bytes
-    int32_t off_mk, off_rec;
+    int32_t off_mk, off_rec, off_P;
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
@@ -146,10 +146,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         if (VEC) {
             for (int q = lane; q < ncell / 4; q += kWave) {
                 int4 v = ((const int4 *)gh)[q];
-                ((uint32_t *)hm)[q] = (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24);
+                ((uint32_t *)hm)[q] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) | (min((uint32_t)v.z, 255u) << 16) |
+                                      (min((uint32_t)v.w, 255u) << 24);
             }
         } else {
-            for (int c = lane; c < ncell; c += kWave) hm[c] = (uint8_t)gh[c];
+            for (int c = lane; c < ncell; c += kWave) hm[c] = (uint8_t)min((uint32_t)gh[c], 255u);
         }
     } else if (MODE == kMaskObs) {
         // acktr/utils.py:41-47: plane 0 of the observation row is the heightmap
@@ -157,13 +158,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             for (int q = lane; q < ncell / 4; q += kWave) {
                 uint32_t el = p.divA4.div(q);  // bin within the wave (A/4 quads per bin)
                 float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * (A / 4)];
-                ((uint32_t *)hm)[q] = (uint32_t)(int)v.x | ((uint32_t)(int)v.y << 8) | ((uint32_t)(int)v.z << 16) |
-                                      ((uint32_t)(int)v.w << 24);
+                ((uint32_t *)hm)[q] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
+                                      (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
             }
         } else {
             for (int c = lane; c < ncell; c += kWave) {
                 uint32_t el = p.divA.div(c);
-                hm[c] = (uint8_t)(int)p.obs_in[(size_t)(e0 + el) * 4 * A + (c - el * A)];
+                hm[c] = (uint8_t)min((uint32_t)(int)p.obs_in[(size_t)(e0 + el) * 4 * A + (c - el * A)], 255u);
             }
         }
     } else {
@@ -369,6 +370,337 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
     }
 }
 
+
+// =================================================================================================
+// Fast path: compile-time geometry + packed-histogram integral image
+// =================================================================================================
+// The generic kernel above walks every candidate's x*y window cell by cell (14 instructions and one
+// LDS round trip per cell).  Here every cell of height h is coded as the 64-bit integer 1 << (5*h)
+// -- a histogram over height levels with 5-bit counters -- and a 2-D inclusive prefix sum P of the
+// codes is built in LDS once per step (two scans).  The histogram of ANY window of <= 31 cells is then
+//   P[i+x][j+y] - P[i][j+y] - P[i+x][j] + P[i][j]          (plain 64-bit integer arithmetic; prefix
+// totals may overflow a field, the final difference cannot), its top set field is max_h and that
+// field's value is max_area: 4 LDS reads + 3 subtractions + one clz per candidate, no loop.
+// 12 levels fit one word (H <= 10 leaves level H+1 for out-of-range inputs), K words cover
+// H + 2 <= 12*K.  Windows of more than 31 cells (the bin-sized terminator item) are tiled into
+// <= 5x6 pieces whose (max, count) pairs are merged.
+constexpr int kFieldBits = 5;
+constexpr int kLevelsPerWord = 12;
+constexpr int kTileX = 5, kTileY = 6;
+
+template <int K>
+struct __attribute__((aligned(8 * K))) Ent {
+    uint64_t w[K];
+};
+
+template <int K>
+__device__ __forceinline__ Ent<K> code_of(uint32_t h) {
+    Ent<K> c;
+    if (K == 1) {
+        c.w[0] = 1ull << (kFieldBits * h);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t rel = h - kLevelsPerWord * k;  // wraps to a huge value when h is below this word
+            c.w[k] = rel < (uint32_t)kLevelsPerWord ? 1ull << (kFieldBits * rel) : 0ull;
+        }
+    }
+    return c;
+}
+
+// Highest non-empty level of a window histogram and the count stored there.
+template <int K>
+__device__ __forceinline__ void top_of(const Ent<K> &h, int &m, int &cnt) {
+    uint64_t v = h.w[0];
+    int word = 0;
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (h.w[k] != 0) {
+            v = h.w[k];
+            word = k;
+        }
+    const int msb = 63 - __builtin_clzll(v);
+    const int lvl = (msb * 13) >> 6;  // msb / 5 for msb <= 63
+    cnt = (int)((v >> (kFieldBits * lvl)) & 31u);
+    m = word * kLevelsPerWord + lvl;
+}
+
+template <int K>
+__device__ __forceinline__ void rect_top(const Ent<K> *P00, int PW, int xa, int yb, int &m, int &cnt) {
+    const Ent<K> a = P00[0], b = P00[yb], c = P00[xa * PW], d = P00[xa * PW + yb];
+    Ent<K> h;
+#pragma unroll
+    for (int k = 0; k < K; ++k) h.w[k] = d.w[k] - b.w[k] - c.w[k] + a.w[k];
+    top_of<K>(h, m, cnt);
+}
+
+// (max_h, max_area) of window [i,i+x) x [j,j+y) from the bin's prefix image (acktr/utils.py:14-16).
+template <int K>
+__device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int j, int x, int y, int &mh, int &ma) {
+    if (x <= kTileX && y <= kTileY) {
+        rect_top<K>(Pb + i * PW + j, PW, x, y, mh, ma);
+        return;
+    }
+    mh = -1;
+    ma = 0;
+    for (int a0 = 0; a0 < x; a0 += kTileX) {
+        const int xa = min(kTileX, x - a0);
+        for (int b0 = 0; b0 < y; b0 += kTileY) {
+            const int yb = min(kTileY, y - b0);
+            int m, c;
+            rect_top<K>(Pb + (i + a0) * PW + (j + b0), PW, xa, yb, m, c);
+            ma = m > mh ? c : ma + (m == mh ? c : 0);
+            mh = max(mh, m);
+        }
+    }
+}
+
+template <int W, int L, int K, bool ROT, int MODE>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const Params p) {
+    constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, PW = L + 1, PN = (W + 1) * (L + 1);
+    static_assert(A % 4 == 0, "fast path needs W*L % 4 == 0");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x >> 6;
+    const int e0 = (blockIdx.x * kWavesPerBlock + wid) * p.epw;
+    if (e0 >= p.E) return;
+    const int nenv = min(p.epw, p.E - e0);
+    unsigned char *wb = smem + wid * p.lds_per_wave;
+    uint8_t *hm = wb;
+    uint32_t *hm32 = (uint32_t *)wb;
+    uint8_t *mk = wb + p.off_mk;
+    BinRec *rec = (BinRec *)(wb + p.off_rec);
+    Ent<K> *P = (Ent<K> *)(wb + p.off_P);
+    const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
+
+    // ---- phase 1: stage heightmaps as bytes ------------------------------------------------------
+    if (MODE == kStep || MODE == kMaskHmap) {
+        const int4 *gh = (const int4 *)((MODE == kStep ? p.hmap : p.hmap_in) + (size_t)e0 * A);
+        for (int q = lane; q < nenv * A4; q += kWave) {
+            const int4 v = gh[q];
+            hm32[q] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) | (min((uint32_t)v.z, 255u) << 16) |
+                      (min((uint32_t)v.w, 255u) << 24);
+        }
+    } else if (MODE == kMaskObs) {
+        for (int q = lane; q < nenv * A4; q += kWave) {
+            const int el = q / A4;
+            const float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * A4];
+            hm32[q] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
+                      (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
+        }
+    } else {
+        for (int q = lane; q < nenv * A4; q += kWave) hm32[q] = 0u;  // space.py:22
+    }
+    wave_sync();
+
+    // ---- phase 2: lane-per-bin scalar work (same semantics as the generic kernel) ---------------
+    if (lane < nenv) {
+        const int e = e0 + lane;
+        BinRec r;
+        r.place = 0;
+        r.flags = 0;
+        r.any = 0;
+        if (MODE == kStep) {
+            bpp_env_state st = p.state[e];
+            const int64_t act = p.actions[e];
+            const int T = p.T;
+            int seq_n = st.seq + p.seq_stride;
+            seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
+            const uint32_t *srow = p.pool + (size_t)st.seq * T;
+            const uint32_t it_cur = srow[min(st.cursor, T - 1)];     // binCreator.py:15-18
+            const uint32_t it_nxt = srow[min(st.cursor + 1, T - 1)];
+            const uint32_t it_rst = p.pool[(size_t)seq_n * T];
+            const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
+            int64_t idx = act;                                       // bin3D.py:96-105
+            const bool flag = ROT && idx > A;
+            if (flag) idx -= A;
+            const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
+            bool ok = idx >= 0 && idx < (int64_t)(W + 1) * L;
+            int lx = 0, ly = 0, top = 0;
+            if (ok) {
+                lx = (int)((uint32_t)idx / (uint32_t)L);             // space.py:153-156
+                ly = (int)idx - lx * L;
+                ok = (lx + x <= W) && (ly + y <= L);                 // space.py:112-115
+            }
+            if (ok) {
+                Win w = scan_window(hm + lane * A, L, lx, ly, x, y);
+                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);     // space.py:117-144
+                top = w.mh + z;                                      // space.py:42-45
+            }
+            const int vol = ix * iy * iz;
+            const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;  // bin3D.py:44-46,108-121
+            st.n_boxes += ok ? 1 : 0;
+            st.vol_sum += ok ? vol : 0;
+            st.ep_ret = st.ep_ret + rew;                             // bench/monitor.py:58-62
+            st.ep_len += 1;
+            p.reward[e] = (float)rew;                                // acktr/envs.py:192
+            p.done[e] = ok ? 0 : 1;
+            p.counter[e] = st.n_boxes;                               // bin3D.py:111,124
+            p.ratio[e] = (double)st.vol_sum / p.binvol;              // space.py:146-151
+            p.ep_ret[e] = st.ep_ret;
+            p.ep_len[e] = st.ep_len;
+            if (ok) {
+                st.cursor += 1;                                      // bin3D.py:116-117
+                r.item = it_nxt;
+                r.flags = 1u;
+                uint8_t *hb = hm + lane * A + lx * L + ly;           // space.py:36-46: window := max_h + z
+                for (int a = 0; a < x; ++a)
+                    for (int b = 0; b < y; ++b) hb[a * L + b] = (uint8_t)top;
+            } else {                                                 // shmem_vec_env.py:128-129
+                st.episode += 1;
+                st.seq = seq_n;
+                st.cursor = 0;
+                st.n_boxes = 0;
+                st.vol_sum = 0;
+                st.ep_ret = 0.0;
+                st.ep_len = 0;
+                r.item = it_rst;
+                r.flags = 2u;
+            }
+            p.state[e] = st;
+        } else if (MODE == kResetInit || MODE == kResetAdvance) {
+            bpp_env_state st;
+            if (MODE == kResetInit) {
+                st.episode = 0;
+                st.seq = (int32_t)(((uint32_t)p.base_mod + (uint32_t)e) % (uint32_t)p.P);
+            } else {
+                st = p.state[e];
+                st.episode += 1;
+                const int sq = st.seq + p.seq_stride;
+                st.seq = sq >= p.P ? sq - p.P : sq;
+            }
+            st.cursor = 0;
+            st.n_boxes = 0;
+            st.vol_sum = 0;
+            st.ep_ret = 0.0;
+            st.ep_len = 0;
+            p.state[e] = st;
+            r.item = p.pool[(size_t)st.seq * p.T];
+        } else if (MODE == kMaskObs) {
+            const float *o = p.obs_in + (size_t)e * 4 * A;           // acktr/utils.py:43-45
+            r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
+        } else {
+            const int32_t *it = p.items_in + (size_t)e * 3;
+            r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
+        }
+        rec[lane] = r;
+    }
+    wave_sync();
+
+    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
+        if (MODE == kStep) {
+            // ---- phase 3a: finished bins restart from an empty map --------------------------------
+            for (int q = lane; q < nenv * A4; q += kWave)
+                if (rec[q / A4].flags & 2u) hm32[q] = 0u;
+            wave_sync();
+        }
+        // ---- phase 3b: int32 heightmap + float32 observation out (bin3D.py:49-66) -----------------
+        int4 *gh = (int4 *)(p.hmap + (size_t)e0 * A);
+        float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
+        for (int q = lane; q < nenv * A4; q += kWave) {
+            const int el = q / A4;
+            const uint32_t v = hm32[q];
+            const int4 iv = make_int4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
+            gh[q] = iv;
+            go[q + el * (3 * A4)] = make_float4((float)iv.x, (float)iv.y, (float)iv.z, (float)iv.w);
+        }
+        for (int g = lane; g < nenv * 3 * A4; g += kWave) {
+            const int el = g / (3 * A4);
+            const int r3 = g - el * (3 * A4);
+            const float f = (float)((rec[el].item >> (8 * (r3 / A4))) & 255u);
+            go[g + (el + 1) * A4] = make_float4(f, f, f, f);
+        }
+        if (p.mask == nullptr) return;
+    }
+
+    // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
+    {
+        Ent<K> zero;
+#pragma unroll
+        for (int k = 0; k < K; ++k) zero.w[k] = 0;
+        for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
+            const int el = t / (PW + W), r = t - el * (PW + W);
+            P[el * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
+        }
+        for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
+            const int el = t / W, i = t - el * W;
+            const uint8_t *row = hm + el * A + i * L;
+            uint32_t hv[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) hv[j] = row[j];
+            Ent<K> *pr = P + el * PN + (i + 1) * PW + 1;
+            Ent<K> s = zero;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+#pragma unroll
+                for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                pr[j] = s;
+            }
+        }
+        wave_sync();
+        for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
+            const int el = t / L, j = t - el * L;
+            Ent<K> *pc = P + el * PN + PW + (j + 1);
+            Ent<K> s = zero;
+            constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
+            for (int i0 = 0; i0 < W; i0 += CH) {
+                Ent<K> v[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
+                    pc[(i0 + i) * PW] = s;
+                }
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94) ----------------
+    for (int c = lane; c < nenv * M; c += kWave) {
+        const int el = c / M;
+        int r = c - el * M;
+        const bool rot = ROT && r >= A;                                // utils.py:81-89
+        if (rot) r -= A;
+        const int i = r / L, j = r - i * L;
+        const uint32_t item = rec[el].item;
+        const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+        const int x = rot ? iy : ix, y = rot ? ix : iy;
+        bool f = false;
+        if (i + x <= W && j + y <= L && x > 0 && y > 0) {              // utils.py:54-55 loop ranges
+            int mh, ma;
+            window_top<K>(P + el * PN, PW, i, j, x, y, mh, ma);
+            const uint8_t *hb = hm + el * A + i * L + j;
+            const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
+            Win w;
+            w.mh = mh;
+            w.ma = ma;
+            w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
+            w.sc = 4;
+            if (p.rule == BPP_RULE_SPACE) {
+                const int rm = max(max(r00, r10), max(r01, r11));
+                w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
+            }
+            f = feasible(w, x * y, z, p.H, p.rule);
+        }
+        mk[c] = f ? 1 : 0;
+        if (f) rec[el].any = 1u;
+    }
+    wave_sync();
+
+    // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
+    {
+        float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
+        for (int g = lane; g < nenv * (M / 4); g += kWave) {
+            const uint32_t v = rec[g / (M / 4)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
+            gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+        }
+    }
+}
+
 // Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
@@ -471,9 +803,17 @@ int check_geometry(int E, int W, int L, int H, int rotation, int rule) {
 struct Launch {
     Params p;
     bool vec;
+    int fast;  // index into the fast-path geometry table, -1 = generic kernel
     int blocks;
     size_t lds;
 };
+
+// Geometries with a compiled fast path: (W, L, K) with K 64-bit histogram words, H + 2 <= 12 * K.
+struct FastGeo {
+    int W, L, K;
+};
+constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}};
+constexpr int kNumFastGeo = sizeof(kFastGeo) / sizeof(kFastGeo[0]);
 
 Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     Launch l;
@@ -493,10 +833,25 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     if (env && atoi(env) > 0) epw = atoi(env) > 64 ? 64 : atoi(env);
     else
         while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16)) > 32 * 1024) epw >>= 1;
+    l.fast = -1;
+    const char *gen = getenv("BPP_FORCE_GENERIC");
+    if (!(gen && atoi(gen) != 0))
+        for (int g = 0; g < kNumFastGeo; ++g)
+            if (kFastGeo[g].W == W && kFastGeo[g].L == L && H + 2 <= kLevelsPerWord * kFastGeo[g].K) {
+                l.fast = g;
+                break;
+            }
+    const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * kFastGeo[l.fast].K : 0;
+    if (l.fast >= 0 && !(env && atoi(env) > 0)) {
+        // prefix image dominates LDS: keep a 4-wave block near 40 KiB (4 blocks = 16 waves per CU)
+        epw = 16;
+        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16 + pn_bytes)) > 40 * 1024) epw >>= 1;
+    }
     p.epw = epw;
     p.off_mk = (epw * p.A + 15) & ~15;
     p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
-    p.lds_per_wave = p.off_rec + epw * (int)sizeof(BinRec);
+    p.off_P = p.off_rec + epw * (int)sizeof(BinRec);
+    p.lds_per_wave = p.off_P + epw * pn_bytes;
     p.divL = make_fastdiv(L);
     p.divA = make_fastdiv(p.A);
     p.divM = make_fastdiv(p.M);
@@ -508,9 +863,24 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     return l;
 }
 
+template <int W, int L, int K, int MODE>
+void launch_fast(const Launch &l, hipStream_t s) {
+    if (l.p.rotation)
+        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, true, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+    else
+        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, false, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+}
+
 template <int MODE>
 int launch(const Launch &l, hipStream_t s) {
-    if (l.vec)
+    if (l.lds > 64 * 1024) return fail(BPP_E_TOOLARGE, "LDS request above 64 KiB per block");
+    if (l.fast == 0)
+        launch_fast<10, 10, 1, MODE>(l, s);
+    else if (l.fast == 1)
+        launch_fast<20, 20, 1, MODE>(l, s);
+    else if (l.fast == 2)
+        launch_fast<20, 20, 2, MODE>(l, s);
+    else if (l.vec)
         hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
     else
         hipLaunchKernelGGL((bpp_kernel<false, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);

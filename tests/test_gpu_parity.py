@@ -20,6 +20,17 @@ def bpp():
     return bpp_amd
 
 
+@pytest.fixture(params=["fast", "generic"])
+def kernel_path(request, monkeypatch):
+    """Every geometry with a compiled fast path (packed-histogram prefix image) is also run through
+    the generic cell-scan kernel; geometries without one run the generic kernel twice (cheap)."""
+    if request.param == "generic":
+        monkeypatch.setenv("BPP_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("BPP_FORCE_GENERIC", raising=False)
+    return request.param
+
+
 class GpuEnv(object):
     """numpy-in/numpy-out adapter so the golden replay helper can drive BppVecEnv."""
 
@@ -39,12 +50,12 @@ class GpuEnv(object):
 
 
 @pytest.mark.parametrize("case", ROLLOUT_CASES)
-def test_gpu_rollout_matches_reference_golden(bpp, case):
+def test_gpu_rollout_matches_reference_golden(bpp, kernel_path, case):
     check_rollout(lambda pool, size, rot, E, rule: GpuEnv(bpp, pool, size, rot, E, rule), load_golden(case))
 
 
 @pytest.mark.parametrize("case", MASK_CASES)
-def test_gpu_masks_match_reference_golden(bpp, case):
+def test_gpu_masks_match_reference_golden(bpp, kernel_path, case):
     rules = {0: "utils", 1: "space"}
     check_masks(lambda obs, size, rot, rule: bpp.batched_mask_from_obs(obs, size, bool(rot), rules[rule]).cpu().numpy(),
                 lambda hm, it, size, rot, rule: bpp.batched_mask_from_hmap(hm, it, size, bool(rot), rules[rule]).cpu().numpy(),
@@ -66,17 +77,21 @@ def test_gpu_dropin_mask_functions(bpp):
 
 
 GEOMS = [((10, 10, 10), False, 1024, 11), ((10, 10, 10), True, 1000, 12), ((20, 20, 20), False, 160, 13),
-         ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16)]
+         ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16),
+         ((20, 20, 10), True, 130, 17), ((20, 20, 22), True, 67, 18), ((10, 10, 7), True, 203, 19),
+         ((10, 10, 11), False, 50, 20)]
 
 
 @pytest.mark.parametrize("size,rot,E,seed", GEOMS)
-def test_gpu_vs_oracle_random_rollout(bpp, oracle, size, rot, E, seed):
+def test_gpu_vs_oracle_random_rollout(bpp, oracle, kernel_path, size, rot, E, seed):
     """Longer seeded rollouts on many bins (incl. bin counts that are not a multiple of the per-wave
     group and non-multiple-of-4 areas): device sampler == oracle sampler, all outputs and the final
     state bit-exact."""
     rng = np.random.RandomState(seed)
     lo, hi = 1, max(2, min(size) // 2)
     seqs = [[tuple(rng.randint(lo, hi + 1, size=3)) for _ in range(rng.randint(3, 60))] for _ in range(37)]
+    seqs[3][1] = (size[0], size[1], 1)       # bin-sized footprints: windows far above 31 cells
+    seqs[5][0] = (size[0], size[1] - 1, 2)
     pool = bpp.sequences.pad_pool(seqs, size)
     for rule in ("utils", "space"):
         env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, mask_rule=rule, env_id_base=5, env_id_total=E + 9)
@@ -128,7 +143,7 @@ def test_gpu_reward_table_all_volumes(bpp, oracle):
 
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 65536), ((10, 10, 10), True, 65536),
                                          ((20, 20, 20), False, 32768)])
-def test_gpu_full_size_properties_and_slices(bpp, oracle, size, rot, E):
+def test_gpu_full_size_properties_and_slices(bpp, oracle, kernel_path, size, rot, E):
     """BASELINE.json's full sizes: size-independent invariants on ALL bins plus bit-exact oracle
     replays of three 192-bin slices (bins are independent and sequences are keyed by global bin id,
     so a slice can be replayed in isolation with env_id_base/env_id_total)."""

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Average every PMC counter per kernel name from rocprofv3 --pmc CSV output directories."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        k = "step" if "bpp_kernel<true, 0>" in k or "bpp_kernel<false, 0>" in k else (
+            "sample" if "sample_kernel" in k else ("stats" if "stats_kernel" in k else None))
+        if k is None:
+            continue
+        a = acc[k][row["Counter_Name"]]
+        a[0] += float(row["Counter_Value"])
+        a[1] += 1
+with open(os.path.join(root, "summary.txt"), "w") as out:
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            s, n = acc[k][c]
+            line = "%-8s %-24s avg %16.1f  (n=%d)" % (k, c, s / n, n)
+            print(line)
+            out.write(line + "\n")
