@@ -46,7 +46,8 @@ struct Params {
     int32_t E, W, L, H, A, M, rotation, rule;
     int32_t epw;           // bins per wave
     int32_t lds_per_wave;  // bytes
-    int32_t off_mk, off_rec, off_P;
+    int32_t off_mk, off_rec, off_ori, off_P;
+    int32_t epw_shift;     // epw == 1 << epw_shift on the fast path
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
@@ -455,6 +456,31 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
     }
 }
 
+// Per-bin, per-orientation constants of the item shown in the next observation, computed once by the
+// bin's lane and read (one ds_read_b128) by every candidate lane.  The float64 ratio tests of
+// acktr/utils.py:28-33 become integer thresholds on max_area:
+//   ma/area > 0.95  <=>  ma >= floor(19*area/20) + 1   (t95), likewise t85 (17/20) and t50 (1/2).
+struct __attribute__((aligned(16))) OriRec {
+    uint32_t a;  // x | y<<8 | (max(H - z + 1, 0))<<16 (9 bits) | big<<25 | valid<<26
+    uint32_t b;  // t95 | t85<<16
+    uint32_t c;  // t50 | (W - x)<<16 | (L - y)<<24
+    uint32_t d;
+};
+
+template <int W, int L>
+__device__ __forceinline__ OriRec make_ori(int x, int y, int z, int H) {
+    OriRec o;
+    const int area = x * y;
+    const uint32_t valid = (x >= 1 && y >= 1 && x <= W && y <= L) ? 1u : 0u;
+    const uint32_t big = (x > kTileX || y > kTileY) ? 1u : 0u;
+    const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
+    o.a = (uint32_t)x | ((uint32_t)y << 8) | (hz1 << 16) | (big << 25) | (valid << 26);
+    o.b = (uint32_t)(19 * area / 20 + 1) | ((uint32_t)(17 * area / 20 + 1) << 16);
+    o.c = (uint32_t)(area / 2 + 1) | ((uint32_t)((W - x) & 255) << 16) | ((uint32_t)((L - y) & 255) << 24);
+    o.d = 0;
+    return o;
+}
+
 template <int W, int L, int K, bool ROT, int MODE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const Params p) {
     constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, PW = L + 1, PN = (W + 1) * (L + 1);
@@ -470,6 +496,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     uint32_t *hm32 = (uint32_t *)wb;
     uint8_t *mk = wb + p.off_mk;
     BinRec *rec = (BinRec *)(wb + p.off_rec);
+    OriRec *ori = (OriRec *)(wb + p.off_ori);  // [epw][2]
     Ent<K> *P = (Ent<K> *)(wb + p.off_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
 
@@ -493,10 +520,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     }
     wave_sync();
 
-    // ---- phase 2: lane-per-bin scalar work (same semantics as the generic kernel) ---------------
-    if (lane < nenv) {
-        const int e = e0 + lane;
+    // ---- phase 2: per-bin scalar work, one sub-group of G = 64/epw lanes per bin ------------------
+    // Every lane of a sub-group carries the bin's scalars redundantly; the placement window is split
+    // by rows over the sub-group and the (max, count) pairs are merged with a butterfly.  Shuffles are
+    // executed by the whole wave (no divergence around them).
+    {
+        const int G = kWave >> p.epw_shift;
+        const int el = lane >> (6 - p.epw_shift);  // bin within the wave
+        const int sl = lane & (G - 1);             // lane within the sub-group
+        const bool active = el < nenv;
+        const int e = e0 + (active ? el : 0);
         BinRec r;
+        r.item = 0;
         r.place = 0;
         r.flags = 0;
         r.any = 0;
@@ -507,46 +542,72 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             int seq_n = st.seq + p.seq_stride;
             seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
             const uint32_t *srow = p.pool + (size_t)st.seq * T;
-            const uint32_t it_cur = srow[min(st.cursor, T - 1)];     // binCreator.py:15-18
+            const uint32_t it_cur = srow[min(st.cursor, T - 1)];       // binCreator.py:15-18
             const uint32_t it_nxt = srow[min(st.cursor + 1, T - 1)];
             const uint32_t it_rst = p.pool[(size_t)seq_n * T];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
-            int64_t idx = act;                                       // bin3D.py:96-105
+            int64_t idx = act;                                         // bin3D.py:96-105
             const bool flag = ROT && idx > A;
             if (flag) idx -= A;
             const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
-            bool ok = idx >= 0 && idx < (int64_t)(W + 1) * L;
-            int lx = 0, ly = 0, top = 0;
+            bool ok = active && idx >= 0 && idx < (int64_t)(W + 1) * L;
+            int lx = 0, ly = 0;
             if (ok) {
-                lx = (int)((uint32_t)idx / (uint32_t)L);             // space.py:153-156
+                lx = (int)((uint32_t)idx / (uint32_t)L);               // space.py:153-156
                 ly = (int)idx - lx * L;
-                ok = (lx + x <= W) && (ly + y <= L);                 // space.py:112-115
+                ok = (lx + x <= W) && (ly + y <= L);                   // space.py:112-115
             }
+            uint8_t *hb = hm + el * A + lx * L + ly;
+            int mh = 0, ma = 0;                                        // space.py:127-129, rows split
+            if (ok)
+                for (int a = sl; a < x; a += G) {
+                    const uint8_t *row = hb + a * L;
+                    for (int b = 0; b < y; ++b) {
+                        const int v = row[b];
+                        ma = v > mh ? 1 : ma + (v == mh);
+                        mh = max(mh, v);
+                    }
+                }
+            for (int d = 1; d < G; d <<= 1) {
+                const int m2 = __shfl_xor(mh, d, kWave), c2 = __shfl_xor(ma, d, kWave);
+                const int nm = max(mh, m2);
+                ma = (mh == nm ? ma : 0) + (m2 == nm ? c2 : 0);
+                mh = nm;
+            }
+            int top = 0;
             if (ok) {
-                Win w = scan_window(hm + lane * A, L, lx, ly, x, y);
-                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);     // space.py:117-144
-                top = w.mh + z;                                      // space.py:42-45
+                const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
+                const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125
+                Win w;
+                w.mh = mh;
+                w.ma = ma;
+                w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
+                w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
+                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);       // space.py:131-144
+                top = mh + z;                                          // space.py:42-45 with lz = max_h
             }
             const int vol = ix * iy * iz;
             const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;  // bin3D.py:44-46,108-121
             st.n_boxes += ok ? 1 : 0;
             st.vol_sum += ok ? vol : 0;
-            st.ep_ret = st.ep_ret + rew;                             // bench/monitor.py:58-62
+            st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
             st.ep_len += 1;
-            p.reward[e] = (float)rew;                                // acktr/envs.py:192
-            p.done[e] = ok ? 0 : 1;
-            p.counter[e] = st.n_boxes;                               // bin3D.py:111,124
-            p.ratio[e] = (double)st.vol_sum / p.binvol;              // space.py:146-151
-            p.ep_ret[e] = st.ep_ret;
-            p.ep_len[e] = st.ep_len;
+            const bool writer = active && sl == 0;
+            if (writer) {
+                p.reward[e] = (float)rew;                              // acktr/envs.py:192
+                p.done[e] = ok ? 0 : 1;
+                p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
+                p.ratio[e] = (double)st.vol_sum / p.binvol;            // space.py:146-151
+                p.ep_ret[e] = st.ep_ret;
+                p.ep_len[e] = st.ep_len;
+            }
             if (ok) {
-                st.cursor += 1;                                      // bin3D.py:116-117
+                st.cursor += 1;                                        // bin3D.py:116-117
                 r.item = it_nxt;
                 r.flags = 1u;
-                uint8_t *hb = hm + lane * A + lx * L + ly;           // space.py:36-46: window := max_h + z
-                for (int a = 0; a < x; ++a)
+                for (int a = sl; a < x; a += G)                        // space.py:36-46: window := max_h + z
                     for (int b = 0; b < y; ++b) hb[a * L + b] = (uint8_t)top;
-            } else {                                                 // shmem_vec_env.py:128-129
+            } else {                                                   // shmem_vec_env.py:128-129
                 st.episode += 1;
                 st.seq = seq_n;
                 st.cursor = 0;
@@ -557,7 +618,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
                 r.item = it_rst;
                 r.flags = 2u;
             }
-            p.state[e] = st;
+            if (writer) p.state[e] = st;
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -574,16 +635,21 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             st.vol_sum = 0;
             st.ep_ret = 0.0;
             st.ep_len = 0;
-            p.state[e] = st;
+            if (active && sl == 0) p.state[e] = st;
             r.item = p.pool[(size_t)st.seq * p.T];
         } else if (MODE == kMaskObs) {
-            const float *o = p.obs_in + (size_t)e * 4 * A;           // acktr/utils.py:43-45
+            const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
             r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
         } else {
             const int32_t *it = p.items_in + (size_t)e * 3;
             r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
         }
-        rec[lane] = r;
+        if (active && sl == 0) {
+            rec[el] = r;
+            const int nx = r.item & 255u, ny = (r.item >> 8) & 255u, nz = (r.item >> 16) & 255u;
+            ori[el * 2] = make_ori<W, L>(nx, ny, nz, p.H);
+            if (ROT) ori[el * 2 + 1] = make_ori<W, L>(ny, nx, nz, p.H);  // utils.py:81-84
+        }
     }
     wave_sync();
 
@@ -662,29 +728,36 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94) ----------------
     for (int c = lane; c < nenv * M; c += kWave) {
         const int el = c / M;
-        int r = c - el * M;
-        const bool rot = ROT && r >= A;                                // utils.py:81-89
-        if (rot) r -= A;
-        const int i = r / L, j = r - i * L;
-        const uint32_t item = rec[el].item;
-        const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-        const int x = rot ? iy : ix, y = rot ? ix : iy;
+        const int r = c - el * M;
+        const int rot = (ROT && r >= A) ? 1 : 0;                       // utils.py:81-89: second half
+        const int cell = r - rot * A;
+        const int i = cell / L, j = cell - i * L;
+        const OriRec o = ori[el * 2 + rot];
+        const int x = o.a & 255u, y = (o.a >> 8) & 255u;
+        const int imax = (o.c >> 16) & 255u, jmax = o.c >> 24;
         bool f = false;
-        if (i + x <= W && j + y <= L && x > 0 && y > 0) {              // utils.py:54-55 loop ranges
+        if ((o.a & (1u << 26)) && i <= imax && j <= jmax) {            // utils.py:54-55 loop ranges
+            const Ent<K> *Pb = P + el * PN + i * PW + j;
             int mh, ma;
-            window_top<K>(P + el * PN, PW, i, j, x, y, mh, ma);
-            const uint8_t *hb = hm + el * A + i * L + j;
-            const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
-            Win w;
-            w.mh = mh;
-            w.ma = ma;
-            w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
-            w.sc = 4;
-            if (p.rule == BPP_RULE_SPACE) {
-                const int rm = max(max(r00, r10), max(r01, r11));
-                w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
+            if (!(o.a & (1u << 25))) {
+                const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                Ent<K> h;
+#pragma unroll
+                for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
+                top_of<K>(h, mh, ma);
+            } else {
+                window_top<K>(P + el * PN, PW, i, j, x, y, mh, ma);
             }
-            f = feasible(w, x * y, z, p.H, p.rule);
+            const uint8_t *hb = hm + el * A + cell;
+            const int o10 = (x - 1) * L, o01 = y - 1;
+            const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+            const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
+            const int thr = cnt == 4 ? (int)(o.c & 0xffffu) : (cnt == 3 ? (int)(o.b >> 16) : (int)(o.b & 0xffffu));
+            f = (mh < (int)((o.a >> 16) & 511u)) && (ma >= thr);       // utils.py:20-33
+            if (p.rule == BPP_RULE_SPACE) {                            // space.py:122-125: sc >= 3
+                const int rm = max(max(r00, r10), max(r01, r11));
+                f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+            }
         }
         mk[c] = f ? 1 : 0;
         if (f) rec[el].any = 1u;
@@ -845,12 +918,19 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     if (l.fast >= 0 && !(env && atoi(env) > 0)) {
         // prefix image dominates LDS: keep a 4-wave block near 40 KiB (4 blocks = 16 waves per CU)
         epw = 16;
-        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16 + pn_bytes)) > 40 * 1024) epw >>= 1;
+        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 48 + pn_bytes)) > 40 * 1024) epw >>= 1;
+    }
+    if (l.fast >= 0) {  // sub-groups of 64/epw lanes per bin: epw must be a power of two <= 64
+        int sh = 0;
+        while ((2 << sh) <= epw && sh < 6) ++sh;
+        epw = 1 << sh;
+        p.epw_shift = sh;
     }
     p.epw = epw;
     p.off_mk = (epw * p.A + 15) & ~15;
     p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
-    p.off_P = p.off_rec + epw * (int)sizeof(BinRec);
+    p.off_ori = p.off_rec + epw * (int)sizeof(BinRec);
+    p.off_P = p.off_ori + (l.fast >= 0 ? epw * 2 * (int)sizeof(OriRec) : 0);
     p.lds_per_wave = p.off_P + epw * pn_bytes;
     p.divL = make_fastdiv(L);
     p.divA = make_fastdiv(p.A);

@@ -11,8 +11,10 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        k = "step" if "bpp_kernel<true, 0>" in k or "bpp_kernel<false, 0>" in k else (
-            "sample" if "sample_kernel" in k else ("stats" if "stats_kernel" in k else None))
+        if ("bpp_kernel<" in k or "bpp_fast_kernel<" in k) and k.split(">(")[0].endswith(", 0"):
+            k = "step"      # MODE == kStep is the last template argument
+        else:
+            k = "sample" if "sample_kernel" in k else ("stats" if "stats_kernel" in k else None)
         if k is None:
             continue
         a = acc[k][row["Counter_Name"]]
