@@ -38,6 +38,8 @@ extern "C" {
 #define BPP_RULE_SPACE 1 /* envs/bpp0/space.py:111-144 Space.check_box -- the placement rule, also
                             used by PackingGame.get_possible_position (envs/bpp0/bin3D.py:72-93)  */
 
+#define BPP_STATS_SLOTS 256
+
 /* bpp_reset modes */
 #define BPP_RESET_INIT    0 /* first reset: episode index 0                                        */
 #define BPP_RESET_ADVANCE 1 /* later VecEnv.reset(): every bin abandons its episode, next sequence */
@@ -72,6 +74,9 @@ typedef struct bpp_batch {
     int32_t *hmap;         /* [E][W*L] Space.plain, row-major idx = lx*L + ly,
                               envs/bpp0/space.py:22,153-156                                        */
     bpp_env_state *state;  /* [E]                                                                  */
+    double *stats;         /* NULL, or [BPP_STATS_SLOTS][4] episode statistics accumulated by bpp_step
+                              (same four sums as bpp_episode_stats, spread over slots to keep the
+                              float64 atomics uncontended; the reader sums over the slot axis)    */
 } bpp_batch;
 
 /* Outputs of one lock-step.  Layout = what VecPyTorch hands the ACKTR loop (acktr/envs.py:170-193)
@@ -119,9 +124,17 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
 
 /* Benchmark/test action source (no reference counterpart; SURVEY.md 8d "actions for timing"):
  * uniform choice among mask==1 entries with a counter-based RNG keyed by (seed, global bin id,
- * step).  actions: [E] int64. */
+ * step): pick = (hash >> 32) * count >> 32, the pick-th set entry in index order.  actions: [E] int64. */
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
                         uint64_t seed, uint64_t step, void *stream);
+
+/* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
+ * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }
+ * on `stream` from one host call.  out->mask must hold the mask of the current observations (as left
+ * by bpp_reset / bpp_step) and is required; actions: [E] int64 scratch that ends up holding the last
+ * actions taken. */
+int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
+                        uint64_t step0, int32_t nsteps, void *stream);
 
 /* Device-side replacement of the training loop's per-bin `infos` scan (main.py:159-162: for every
  * finished episode append info['episode']['r'] and info['ratio'] to the logging deques):

@@ -16,9 +16,10 @@ HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 ABI_VERSION = 1
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
+STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
-           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats"]
+           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform"]
 
 
 class Batch(ctypes.Structure):
@@ -26,7 +27,8 @@ class Batch(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
-                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("stats", ctypes.c_void_p)]
 
 
 class StepOut(ctypes.Structure):
@@ -73,6 +75,8 @@ def lib():
         L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
         L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.bpp_rollout_uniform.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
+                                          ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         if L.bpp_abi_version() != ABI_VERSION:
             raise RuntimeError("libbpp_hip.so ABI version %d != %d" % (L.bpp_abi_version(), ABI_VERSION))

@@ -56,6 +56,7 @@ struct Params {
     // state
     int32_t *hmap;
     bpp_env_state *state;
+    double *stats;  // [BPP_STATS_SLOTS][4] or nullptr
     const int64_t *actions;
     // mask-only inputs
     const float *obs_in;
@@ -125,12 +126,34 @@ __device__ __forceinline__ bool feasible(const Win &w, int area, int z, int H, i
     return ok;
 }
 
+// Episode statistics of bins that finished this step (main.py:159-162), summed over the wave and added
+// to one of BPP_STATS_SLOTS slots with four float64 atomics per wave that saw a finished episode.
+// Must be called by the whole wave; `fin` marks the lanes that carry a finished bin.
+__device__ __forceinline__ void wave_episode_stats(double *stats, int slot, bool fin, double ret, double ratio, int len) {
+    if (__ballot(fin) == 0ull) return;
+    double s0 = fin ? ret : 0.0, s1 = fin ? ratio : 0.0, s2 = fin ? (double)len : 0.0, s3 = fin ? 1.0 : 0.0;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        s0 += __shfl_down(s0, d, kWave);
+        s1 += __shfl_down(s1, d, kWave);
+        s2 += __shfl_down(s2, d, kWave);
+        s3 += __shfl_down(s3, d, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        double *a = stats + 4 * (slot & (BPP_STATS_SLOTS - 1));
+        atomicAdd(a + 0, s0);
+        atomicAdd(a + 1, s1);
+        atomicAdd(a + 2, s2);
+        atomicAdd(a + 3, s3);
+    }
+}
+
 template <bool VEC, int MODE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * kWavesPerBlock + wid) * p.epw;
+    const int e0 = (blockIdx.x * (blockDim.x >> 6) + wid) * p.epw;
     if (e0 >= p.E) return;  // no block-level barrier is ever used, a whole wave may leave
     const int nenv = min(p.epw, p.E - e0);
     const int A = p.A, L = p.L, M = p.M;
@@ -178,6 +201,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
     wave_sync();
 
     // ---- phase 2: lane-per-bin scalar work ------------------------------------------------------
+    bool fin = false;
+    double fin_ret = 0.0, fin_ratio = 0.0;
+    int fin_len = 0;
     if (lane < nenv) {
         const int e = e0 + lane;
         BinRec r;
@@ -227,6 +253,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
             p.ep_ret[e] = st.ep_ret;
             p.ep_len[e] = st.ep_len;
+            fin = !ok;
+            fin_ret = st.ep_ret;
+            fin_ratio = (double)st.vol_sum / p.binvol;
+            fin_len = st.ep_len;
             if (ok) {
                 st.cursor += 1;  // bin3D.py:116-117
                 r.item = it_nxt;
@@ -273,6 +303,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         }
         rec[lane] = r;
     }
+    if (MODE == kStep && p.stats) wave_episode_stats(p.stats, e0 / p.epw, fin, fin_ret, fin_ratio, fin_len);
     wave_sync();
 
     if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * kWavesPerBlock + wid) * p.epw;
+    const int e0 = (blockIdx.x * (blockDim.x >> 6) + wid) * p.epw;
     if (e0 >= p.E) return;
     const int nenv = min(p.epw, p.E - e0);
     unsigned char *wb = smem + wid * p.lds_per_wave;
@@ -593,14 +624,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
             st.ep_len += 1;
             const bool writer = active && sl == 0;
+            const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
             if (writer) {
                 p.reward[e] = (float)rew;                              // acktr/envs.py:192
                 p.done[e] = ok ? 0 : 1;
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
-                p.ratio[e] = (double)st.vol_sum / p.binvol;            // space.py:146-151
+                p.ratio[e] = ratio;
                 p.ep_ret[e] = st.ep_ret;
                 p.ep_len[e] = st.ep_len;
             }
+            if (p.stats) wave_episode_stats(p.stats, e0 >> p.epw_shift, writer && !ok, st.ep_ret, ratio, st.ep_len);
             if (ok) {
                 st.cursor += 1;                                        // bin3D.py:116-117
                 r.item = it_nxt;
@@ -782,23 +815,71 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t 
     return z ^ (z >> 31);
 }
 
-// One wave per bin: lanes count set entries of their slice, an inclusive wave scan locates the
-// pick-th one.
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void sample_kernel(const float *mask, int64_t *actions, int E,
-                                                                        int M, int64_t env_id_base, uint64_t seed,
-                                                                        uint64_t step) {
+// Sub-groups of 16 lanes per bin (4 bins per wave): each lane owns `per` consecutive float4 quads of
+// the bin's mask row (16-byte loads), an inclusive scan inside the 16-lane row locates the pick-th set
+// entry in index order.  pick = (hash >> 32) * count >> 32.
+template <int PER>
+__global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t *actions, int E, int M,
+                                                     int64_t env_id_base, uint64_t seed, uint64_t step) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid >> 4, sl = threadIdx.x & 15;
+    const bool active = e < E;
+    const float4 *m = (const float4 *)(mask + (size_t)(active ? e : 0) * M);
+    const int nq = M >> 2;
+    float4 q[PER];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int qi = sl * PER + k;
+        q[k] = (active && qi < nq) ? m[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cnt += (q[k].x != 0.f) + (q[k].y != 0.f) + (q[k].z != 0.f) + (q[k].w != 0.f);
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(incl, d, 16);
+        if (sl >= d) incl += o;
+    }
+    const int total = __shfl(incl, 15, 16);
+    if (!active) return;
+    if (total == 0) {
+        if (sl == 0) actions[e] = 0;
+        return;
+    }
+    int pick = (int)(((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)total) >> 32);
+    const int excl = incl - cnt;
+    if (pick >= excl && pick < incl) {
+        pick -= excl;
+        int found = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (v[t] != 0.f) {
+                    if (c == pick) found = (sl * PER + k) * 4 + t;
+                    ++c;
+                }
+        }
+        actions[e] = found;
+    }
+}
+
+// Fallback for rows that are not a multiple of 4 floats or longer than 16 * 8 quads: one wave per bin.
+__global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, int64_t *actions, int E, int M,
+                                                             int64_t env_id_base, uint64_t seed, uint64_t step) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
     const float *m = mask + (size_t)e * M;
-    const int per = (M + kWave - 1) / kWave;  // contiguous entries per lane
-    const int b = lane * per, en = min(b + per, M);
+    const int per = (M + kWave - 1) / kWave;
+    const int b = min(lane * per, M), en = min(b + per, M);
     int cnt = 0;
     for (int k = b; k < en; ++k) cnt += (m[k] != 0.0f);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
-        int o = __shfl_up(incl, d, kWave);
+        const int o = __shfl_up(incl, d, kWave);
         if (lane >= d) incl += o;
     }
     const int total = __shfl(incl, kWave - 1, kWave);
@@ -806,7 +887,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sample_kernel(const fl
         if (lane == 0) actions[e] = 0;
         return;
     }
-    int pick = (int)(mix64(seed, (uint64_t)(env_id_base + e), step) % (uint64_t)total);
+    int pick = (int)(((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)total) >> 32);
     const int excl = incl - cnt;
     if (pick >= excl && pick < incl) {
         pick -= excl;
@@ -821,18 +902,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sample_kernel(const fl
     }
 }
 
-// Episode statistics of the finished bins (main.py:159-162): per-lane partial sums, wave shuffle
-// reduction, one float64 atomic per wave and statistic.
+// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.stats.
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
                                                     const int32_t *ep_len, int E, double *acc) {
+    __shared__ double red[4][4];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
-        if (done[e]) {
-            s0 += ep_ret[e];
-            s1 += ratio[e];
-            s2 += (double)ep_len[e];
-            s3 += 1.0;
-        }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const double f = done[e] ? 1.0 : 0.0;
+        s0 += f * ep_ret[e];
+        s1 += f * ratio[e];
+        s2 += f * (double)ep_len[e];
+        s3 += f;
+    }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
         s0 += __shfl_down(s0, d, kWave);
@@ -840,11 +921,17 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const d
         s2 += __shfl_down(s2, d, kWave);
         s3 += __shfl_down(s3, d, kWave);
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && s3 != 0.0) {
-        atomicAdd(acc + 0, s0);
-        atomicAdd(acc + 1, s1);
-        atomicAdd(acc + 2, s2);
-        atomicAdd(acc + 3, s3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        red[w][0] = s0;
+        red[w][1] = s1;
+        red[w][2] = s2;
+        red[w][3] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v != 0.0) atomicAdd(acc + threadIdx.x, v);
     }
 }
 
@@ -877,6 +964,7 @@ struct Launch {
     Params p;
     bool vec;
     int fast;  // index into the fast-path geometry table, -1 = generic kernel
+    int wpb;   // waves per workgroup (waves are independent; this only sets the LDS/dispatch granule)
     int blocks;
     size_t lds;
 };
@@ -916,9 +1004,10 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
             }
     const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * kFastGeo[l.fast].K : 0;
     if (l.fast >= 0 && !(env && atoi(env) > 0)) {
-        // prefix image dominates LDS: keep a 4-wave block near 40 KiB (4 blocks = 16 waves per CU)
+        // prefix image dominates LDS: keep a 4-wave block near 20 KiB (8 blocks = 32 waves per CU);
+        // measured best on MI355X for the 10x10 bin (EPW=4: 41 us vs 45 us at EPW=8, 49 us at EPW=2)
         epw = 16;
-        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 48 + pn_bytes)) > 40 * 1024) epw >>= 1;
+        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 48 + pn_bytes)) > 20 * 1024) epw >>= 1;
     }
     if (l.fast >= 0) {  // sub-groups of 64/epw lanes per bin: epw must be a power of two <= 64
         int sh = 0;
@@ -938,17 +1027,20 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     p.divA4 = make_fastdiv(l.vec ? p.A / 4 : p.A);
     p.binvol = (double)W * (double)L * (double)H;
     const int waves = (E + epw - 1) / epw;
-    l.blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    l.lds = (size_t)kWavesPerBlock * p.lds_per_wave;
+    l.wpb = kWavesPerBlock;
+    const char *wpb = getenv("BPP_WPB");
+    if (wpb && atoi(wpb) >= 1 && atoi(wpb) <= kWavesPerBlock) l.wpb = atoi(wpb);
+    l.blocks = (waves + l.wpb - 1) / l.wpb;
+    l.lds = (size_t)l.wpb * p.lds_per_wave;
     return l;
 }
 
 template <int W, int L, int K, int MODE>
 void launch_fast(const Launch &l, hipStream_t s) {
     if (l.p.rotation)
-        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, true, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, true, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
     else
-        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, false, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, false, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
 }
 
 template <int MODE>
@@ -961,9 +1053,9 @@ int launch(const Launch &l, hipStream_t s) {
     else if (l.fast == 2)
         launch_fast<20, 20, 2, MODE>(l, s);
     else if (l.vec)
-        hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+        hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
     else
-        hipLaunchKernelGGL((bpp_kernel<false, MODE>), dim3(l.blocks), dim3(kWave * kWavesPerBlock), l.lds, s, l.p);
+        hipLaunchKernelGGL((bpp_kernel<false, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
@@ -987,6 +1079,7 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.pool = (const uint32_t *)b->seq_pool;
     p.hmap = b->hmap;
     p.state = b->state;
+    p.stats = b->stats;
     p.obs = out->obs;
     p.mask = out->mask;
     p.reward = out->reward;
@@ -1065,18 +1158,48 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
                         uint64_t step, void *stream) {
     if (!mask || !actions) return fail(BPP_E_BADARG, "bpp_sample_feasible: NULL pointer");
     if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_sample_feasible: non-positive size");
-    const int blocks = (E + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, mask, actions,
-                       E, M, env_id_base, seed, step);
+    hipStream_t st = (hipStream_t)stream;
+    const int nq = M / 4;
+    const int per = (nq + 15) / 16;
+    if (M % 4 == 0 && per <= 8 && (((uintptr_t)mask) & 15u) == 0) {
+        const int blocks = (E + 15) / 16;  // 16 bins per 256-thread block
+#define BPP_SAMPLE(P) hipLaunchKernelGGL(sample_kernel<P>, dim3(blocks), dim3(256), 0, st, mask, actions, E, M, env_id_base, seed, step)
+        switch (per) {
+            case 1: BPP_SAMPLE(1); break;
+            case 2: BPP_SAMPLE(2); break;
+            case 3: BPP_SAMPLE(3); break;
+            case 4: BPP_SAMPLE(4); break;
+            case 5: case 6: BPP_SAMPLE(6); break;
+            default: BPP_SAMPLE(8); break;
+        }
+#undef BPP_SAMPLE
+    } else {
+        hipLaunchKernelGGL(sample_kernel_generic, dim3((E + 3) / 4), dim3(256), 0, st, mask, actions, E, M, env_id_base,
+                           seed, step);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
+                        int32_t nsteps, void *stream) {
+    if (!b || !out || !out->mask || !actions) return fail(BPP_E_BADARG, "bpp_rollout_uniform: NULL pointer");
+    if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform: negative nsteps");
+    const int M = b->W * b->L * (1 + b->rotation);
+    for (int t = 0; t < nsteps; ++t) {
+        int rc = bpp_sample_feasible(out->mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t, stream);
+        if (rc) return rc;
+        rc = bpp_step(b, actions, out, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len, int32_t E,
                       double *acc, void *stream) {
     if (!done || !ep_ret || !ratio || !ep_len || !acc) return fail(BPP_E_BADARG, "bpp_episode_stats: NULL pointer");
     if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_stats: non-positive size");
-    const int blocks = (E + 1023) / 1024 < 256 ? (E + 1023) / 1024 : 256;
+    const int blocks = (E + 255) / 256 < 256 ? (E + 255) / 256 : 256;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, E, acc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");

@@ -26,8 +26,14 @@ class EpisodeStats(object):
         self.device = torch.device(device)
         self.acc = torch.zeros(4, dtype=torch.float64, device=self.device)
 
+    def collect(self, env, reset=True):
+        """Add (and by default clear) the statistics BppVecEnv accumulated inside its step kernels."""
+        self.acc += env.episode_stats(reset=reset)
+        return self
+
     def update(self, res):
-        """Add the episodes that finished in step result `res` (StepTensors); enqueues one small kernel."""
+        """Add the episodes that finished in step result `res` (StepTensors) with the stand-alone kernel
+        (for callers that do not use the accumulator built into bpp_step)."""
         if self.device.type != "cuda":
             raise RuntimeError("EpisodeStats.update runs the HIP kernel; device tensors required")
         with torch.cuda.device(self.device):

@@ -133,9 +133,13 @@ class BppVecEnv(object):
             self.pool = torch.from_numpy(self.pool_host).to(dev)
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.int32, device=dev)
             self.state = torch.zeros((self.E, 8), dtype=torch.int32, device=dev)  # bpp_env_state[E], 32 B each
+            # episode statistics accumulated inside the step kernel: [slots][return, ratio, length, count]
+            self.stats_slots = torch.zeros((_lib.STATS_SLOTS, 4), dtype=torch.float64, device=dev)
         self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
                                  self.pool_host.shape[0], self.pool_host.shape[1], self.env_id_base, self.env_id_total,
-                                 self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr())
+                                 self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr(),
+                                 self.stats_slots.data_ptr())
+        self._batch_ref = ctypes.byref(self._batch)
         self._bufs = None
         self._out = None
         self._res = None
@@ -168,13 +172,20 @@ class BppVecEnv(object):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _on_device(self):
+        """HIP launches target the calling thread's current device: make sure it is ours (cheap check,
+        the context switch only happens when it is not)."""
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
+
     # ------------------------------------------------------------------ VecEnv interface
     def reset(self):
         """All bins start a fresh episode (next sequence of their stride); returns obs [E,4A] float32."""
-        with torch.cuda.device(self.device):
-            bufs, out = self._buffers()
-            mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
-            _lib.check(self.lib.bpp_reset(ctypes.byref(self._batch), mode, ctypes.byref(out), self._stream()))
+        self._on_device()
+        bufs, out = self._buffers()
+        self._res = StepTensors(**bufs)
+        mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
+        _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(out), self._stream()))
         self._first_reset = False
         self._tstart = time.time()
         self.location_masks = bufs["mask"]
@@ -192,11 +203,30 @@ class BppVecEnv(object):
             raise ValueError("expected %d actions, got %d" % (self.E, a.numel()))
         if a.device != self.device or a.dtype != torch.int64 or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.int64).contiguous()
-        with torch.cuda.device(self.device):
-            bufs, out = self._buffers()
-            _lib.check(self.lib.bpp_step(ctypes.byref(self._batch), a.data_ptr(), ctypes.byref(out), self._stream()))
-        self.location_masks = bufs["mask"]
-        self._res = StepTensors(**bufs)
+        self._on_device()
+        if self.fresh_outputs or self._bufs is None:
+            self._bufs, self._out = self._alloc()
+            self._res = StepTensors(**self._bufs)
+            self.location_masks = self._bufs["mask"]
+        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(self._out), self._stream())
+        if rc:
+            _lib.check(rc)
+        return self._res
+
+    def rollout_uniform(self, seed, step0, nsteps, actions=None):
+        """`nsteps` lock-steps under the uniform-random-feasible policy, enqueued by ONE native call
+        (bpp_rollout_uniform): no per-step Python.  Returns the StepTensors of the last step."""
+        if self._first_reset:
+            raise RuntimeError("call reset() before rollout_uniform()")
+        if not self.compute_mask:
+            raise RuntimeError("rollout_uniform needs compute_mask=True")
+        if self.fresh_outputs:
+            raise RuntimeError("rollout_uniform reuses one set of output buffers (fresh_outputs=False)")
+        if actions is None:
+            actions = torch.empty((self.E,), dtype=torch.int64, device=self.device)
+        self._on_device()
+        _lib.check(self.lib.bpp_rollout_uniform(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
+                                                int(step0), int(nsteps), self._stream()))
         return self._res
 
     def step_async(self, actions):
@@ -227,10 +257,20 @@ class BppVecEnv(object):
             raise RuntimeError("no mask available (compute_mask=False?)")
         if out is None:
             out = torch.empty((self.E,), dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.bpp_sample_feasible(m.data_ptr(), out.data_ptr(), self.E, m.shape[1],
-                                                    self.env_id_base, int(seed), int(step), self._stream()))
+        self._on_device()
+        rc = self.lib.bpp_sample_feasible(m.data_ptr(), out.data_ptr(), self.E, m.shape[1], self.env_id_base, int(seed),
+                                          int(step), self._stream())
+        if rc:
+            _lib.check(rc)
         return out
+
+    def episode_stats(self, reset=False):
+        """float64 [4] device tensor: sum of episode returns, sum of final ratios, sum of episode lengths,
+        number of episodes finished since the last reset of the accumulator (main.py:159-162)."""
+        acc = self.stats_slots.sum(0)
+        if reset:
+            self.stats_slots.zero_()
+        return acc
 
     def state_dict(self):
         """Env checkpoint (the reference never checkpoints env state; a handful of tensors here)."""

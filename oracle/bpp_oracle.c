@@ -250,6 +250,12 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         out->ep_len[e] = s->ep_len;
         out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
         out->done[e] = (uint8_t)done;
+        if (done && b->stats) {                         /* main.py:159-162 */
+            b->stats[0] += s->ep_ret;
+            b->stats[1] += out->ratio[e];
+            b->stats[2] += (double)s->ep_len;
+            b->stats[3] += 1.0;
+        }
         if (done) {                                     /* shmem_vec_env.py:128-129 */
             s->episode += 1;
             reset_bin(b, e, s);
@@ -310,7 +316,7 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
             actions[e] = 0;
             continue;
         }
-        uint64_t pick = mix64(seed, (uint64_t)(env_id_base + e), step) % (uint64_t)cnt;
+        uint64_t pick = ((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)cnt) >> 32;
         int64_t a = 0;
         for (int k = 0; k < M; ++k)
             if (m[k] != 0.0f) {
@@ -337,5 +343,19 @@ int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *r
             acc[2] += (double)ep_len[e];
             acc[3] += 1.0;
         }
+    return 0;
+}
+
+int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
+                        uint64_t step0, int32_t nsteps, void *stream) {
+    if (!b || !out || !out->mask || !actions) return fail(BPP_E_BADARG, "bpp_rollout_uniform: NULL pointer");
+    if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform: negative nsteps");
+    int M = b->W * b->L * (1 + b->rotation);
+    for (int t = 0; t < nsteps; ++t) {
+        int rc = bpp_sample_feasible(out->mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t, stream);
+        if (rc) return rc;
+        rc = bpp_step(b, actions, out, stream);
+        if (rc) return rc;
+    }
     return 0;
 }

@@ -25,7 +25,8 @@ class Batch(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
-                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+                ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("stats", ctypes.c_void_p)]
 
 
 class StepOut(ctypes.Structure):
@@ -57,6 +58,8 @@ def lib():
         L.bpp_mask_from_hmap.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 6 + [ctypes.c_void_p]
         L.bpp_sample_feasible.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.bpp_rollout_uniform.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
+                                          ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -88,10 +91,11 @@ class OracleEnv(object):
                         reward=np.zeros(self.E, np.float32), done=np.zeros(self.E, np.uint8),
                         counter=np.zeros(self.E, np.int32), ratio=np.zeros(self.E, np.float64),
                         ep_ret=np.zeros(self.E, np.float64), ep_len=np.zeros(self.E, np.int32))
+        self.stats = np.zeros((256, 4), np.float64)
         self._b = Batch(self.E, self.W, self.L, self.H, self.rotation, int(mask_rule), self.pool.shape[0],
                         self.pool.shape[1], int(env_id_base),
                         int(env_id_total if env_id_total is not None else env_id_base + self.E),
-                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value)
+                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.stats).value)
         self._o = StepOut(*[_p(self.out[k]).value for k in ("obs", "mask", "reward", "done", "counter", "ratio",
                                                               "ep_ret", "ep_len")])
         self._first = True
@@ -107,6 +111,14 @@ class OracleEnv(object):
         assert a.shape[0] == self.E
         _check(lib().bpp_step(ctypes.byref(self._b), _p(a), ctypes.byref(self._o), None))
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
+
+
+def rollout_uniform(env, seed, step0, nsteps):
+    """nsteps lock-steps of OracleEnv `env` under the uniform-feasible policy; returns env.out (views)."""
+    a = np.zeros(env.E, np.int64)
+    _check(lib().bpp_rollout_uniform(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
+                                     int(nsteps), None))
+    return env.out, a
 
 
 def mask_from_obs(obs, size, rotation, rule=RULE_UTILS):

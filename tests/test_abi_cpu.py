@@ -43,7 +43,7 @@ def test_abi_version_and_limits(lib):
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Batch) == 8 * 4 + 2 * 8 + 3 * 8
+    assert ctypes.sizeof(_lib.Batch) == 8 * 4 + 2 * 8 + 4 * 8
     assert _lib.Batch.env_id_base.offset == 32 and _lib.Batch.seq_pool.offset == 48
     assert ctypes.sizeof(_lib.StepOut) == 64
     from oracle import oracle as orc
@@ -51,11 +51,11 @@ def test_struct_layouts_match_header():
 
 
 def test_argument_validation_happens_before_any_device_work(lib):
-    b = _lib.Batch(16, 10, 10, 10, 0, 0, 4, 8, 0, 16, None, None, None)
+    b = _lib.Batch(16, 10, 10, 10, 0, 0, 4, 8, 0, 16, None, None, None, None)
     o = _lib.StepOut()
     assert lib.bpp_reset(ctypes.byref(b), 0, ctypes.byref(o), None) == -1
     assert b"NULL" in lib.bpp_last_error()
-    b2 = _lib.Batch(16, 64, 64, 10, 0, 0, 4, 8, 0, 16, 16, 16, 16)
+    b2 = _lib.Batch(16, 64, 64, 10, 0, 0, 4, 8, 0, 16, 16, 16, 16, None)
     assert lib.bpp_step(ctypes.byref(b2), 16, ctypes.byref(o), None) == -2   # W*L > 1024
     assert b"too large" in lib.bpp_last_error()
     assert lib.bpp_mask_from_obs(None, None, 1, 10, 10, 10, 0, 0, None) == -1

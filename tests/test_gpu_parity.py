@@ -199,3 +199,45 @@ def test_gpu_full_size_properties_and_slices(bpp, oracle, kernel_path, size, rot
             n_done += int(done.sum())
         ret_sum[done] = 0
     assert n_done > 0
+
+
+def test_gpu_fused_episode_stats_and_standalone_kernel(bpp, oracle):
+    """The statistics accumulated inside bpp_step (slotted float64 atomics) and by the stand-alone
+    bpp_episode_stats kernel equal the oracle's sequential sums up to float64 summation order."""
+    size, E = (10, 10, 10), 3000
+    pool = bpp.sequences.cut2_pool(size, 64, seed=5)
+    env = bpp.BppVecEnv(E, size, enable_rotation=True, pool=pool)
+    ref = oracle.OracleEnv(pool, size, True, E)
+    env.reset(), ref.reset()
+    standalone = bpp.EpisodeStats(env.device)
+    for t in range(30):
+        a = env.sample_feasible(seed=2, step=t)
+        r = env.step_tensors(a)
+        standalone.update(r)
+        ref.step(a.cpu().numpy())
+    fused = env.episode_stats().cpu().numpy()
+    want = ref.stats.sum(0)
+    assert want[3] > 100
+    np.testing.assert_array_equal(fused[2:], want[2:])                 # lengths and counts are exact integers
+    np.testing.assert_allclose(fused[:2], want[:2], rtol=1e-12)
+    np.testing.assert_allclose(standalone.acc.cpu().numpy(), want, rtol=1e-12)
+    s = bpp.EpisodeStats(env.device).collect(env).summary()
+    assert s["episodes"] == int(want[3]) and abs(s["mean_ratio"] - want[1] / want[3]) < 1e-12
+    assert float(env.episode_stats().sum()) == 0.0                      # collect() cleared the accumulator
+
+
+def test_gpu_native_rollout_driver_matches_oracle(bpp, oracle):
+    """bpp_rollout_uniform (N lock-steps enqueued by one native call) == the oracle's same driver."""
+    size, E = (10, 10, 10), 4096
+    pool = bpp.sequences.cut2_pool(size, 128, seed=7)
+    for rot in (False, True):
+        env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool)
+        ref = oracle.OracleEnv(pool, size, rot, E)
+        env.reset(), ref.reset()
+        r = env.rollout_uniform(seed=11, step0=3, nsteps=37)
+        o, last_a = oracle.rollout_uniform(ref, 11, 3, 37)
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg=k)
+        np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
+        np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+        np.testing.assert_array_equal(env.state_numpy()["episode"], ref.state["episode"])
