@@ -4,6 +4,7 @@ Import as `bpp_amd` (the loader module at the repository root); the directory na
 valid Python identifier."""
 from . import _lib, sequences  # noqa: F401
 from ._lib import build  # noqa: F401
+from .factory import make_pool, make_vec_envs  # noqa: F401
 from .masks import (batched_mask_from_hmap, batched_mask_from_obs, get_possible_position,  # noqa: F401
                     get_rotation_mask)
 from .spaces import Box, Discrete  # noqa: F401
@@ -11,4 +12,4 @@ from .stats import EpisodeStats, shard_range  # noqa: F401
 from .vec_env import BppVecEnv, LazyInfos, StepTensors  # noqa: F401
 
 __all__ = ["BppVecEnv", "LazyInfos", "StepTensors", "Box", "Discrete", "batched_mask_from_obs",
-           "batched_mask_from_hmap", "get_possible_position", "get_rotation_mask", "build", "sequences", "EpisodeStats", "shard_range"]
+           "batched_mask_from_hmap", "get_possible_position", "get_rotation_mask", "build", "sequences", "EpisodeStats", "shard_range", "make_vec_envs", "make_pool"]

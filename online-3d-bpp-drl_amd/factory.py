@@ -1,0 +1,43 @@
+"""`make_vec_envs` with the reference's signature (acktr/envs.py:77-118) returning a BppVecEnv.
+
+    envs = make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets, args=args)
+
+`args` is the reference's argparse namespace (acktr/arguments.py): `container_size`, `enable_rotation`,
+`data_type` ('cut1' | 'cut2' | 'rs', bin3D.py:21-32) and `box_size_set` are honoured; `gamma`, `log_dir`,
+`allow_early_resets`, `num_frame_stack` are accepted for signature compatibility (the reference disables
+VecNormalize's filters anyway, acktr/envs.py:112; Monitor csv files are not written -- episode
+statistics come from `infos`/`EpisodeStats`).  Unlike the reference, `seed` really seeds the item
+sequences (the reference's `env.seed` is a no-op and its forked workers all draw the same stream)."""
+from . import sequences
+from .vec_env import BppVecEnv
+
+
+def make_pool(container_size, data_type="cut2", box_size_set=None, enable_rotation=False, seed=0, pool_size=4096):
+    size = tuple(int(v) for v in container_size)
+    if box_size_set:
+        lo = tuple(int(v) for v in box_size_set[0])
+        hi = tuple(int(v) for v in box_size_set[-1])
+    else:
+        lo, hi = (2, 2, 2), (5, 5, 5)
+    if data_type == "cut2":       # bin3D.py:30-32: MDlayerBoxCreator(container_size, [box_set[0][0], box_set[-1][0]])
+        return sequences.cut2_pool(size, pool_size, seed=seed, bound=(lo[0], hi[0]))
+    if data_type == "cut1":       # bin3D.py:24-29: CuttingBoxCreator(container_size, low + up, can_rotate)
+        return sequences.cut1_pool(size, pool_size, seed=seed, box_range=lo + hi, rotation=enable_rotation)
+    if data_type == "rs":         # bin3D.py:21-23: RandomBoxCreator(box_set); enough items to fill any bin
+        vmin = max(1, min(x * y * z for x, y, z in (box_size_set or [lo])))
+        length = min(4096, size[0] * size[1] * size[2] // vmin + 2)
+        return sequences.rs_pool(size, pool_size, length, seed=seed, box_set=box_size_set)
+    raise ValueError("unknown data_type %r" % (data_type,))
+
+
+def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets,
+                  num_frame_stack=None, args=None, pool=None, pool_size=4096, **env_kwargs):
+    if args is None:
+        raise ValueError("args (the reference's argparse namespace) is required")
+    size = tuple(int(v) for v in args.container_size)
+    rot = bool(getattr(args, "enable_rotation", False))
+    if pool is None:
+        pool = make_pool(size, getattr(args, "data_type", getattr(args, "item_seq", "cut2")),
+                         getattr(args, "box_size_set", None), rot, seed=int(seed), pool_size=pool_size)
+    env_kwargs.setdefault("fresh_outputs", True)   # reference semantics: earlier results stay valid
+    return BppVecEnv(int(num_processes), size, enable_rotation=rot, pool=pool, device=device, **env_kwargs)

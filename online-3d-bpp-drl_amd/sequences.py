@@ -107,6 +107,83 @@ def cut2_pool(container_size, n, seed=0, bound=(2, 5), T=None):
     return pad_pool(seqs, container_size, T)
 
 
+class _Meta(object):
+    __slots__ = ("x", "y", "z", "lx", "ly", "lz")
+
+    def __init__(self, x, y, z, lx, ly, lz):
+        self.x, self.y, self.z, self.lx, self.ly, self.lz = x, y, z, lx, ly, lz
+
+
+def cut1_sequence(container_size, box_range, rng, rotation=False, np_rng=None):
+    """One CUT-1 item sequence.  Restates envs/bpp0/cutCreator.py:32-128: guillotine-cut the bin until
+    every piece is inside `box_range` = (low_x, low_y, low_z, high_x, high_y, high_z) (`_cut_box`,
+    :78-95, `_choose_pos` :58-76), then repeatedly draw a random piece whose support is complete
+    (`_add_candidate` :97-106, `generate_box_size` :111-128).  The draw order does not depend on where the
+    agent puts the items, so the whole sequence can be generated up front.  With `rotation` the reference
+    swaps x/y of an item when np.random.rand() >= 0.5 (:119-125); pass `np_rng` (numpy RandomState)."""
+    low_x, low_y, low_z, high_x, high_y, high_z = box_range
+    W, L, H = container_size
+    meta = [_Meta(W, L, H, 0, 0, 0)]
+    again = True
+    while again:                                     # cutCreator.py:78-95
+        again = False
+        new = []
+        for b in meta:
+            check = ((b.x < low_x or b.x > high_x) * 1 + (b.y < low_y or b.y > high_y) * 2 +
+                     (b.z < low_z or b.z > high_z) * 4)
+            if check == 0:
+                new.append(b)
+                continue
+            df_list = [d for d, bit in ((0, 1), (1, 2), (2, 4)) if check & bit]
+            df = rng.choice(df_list)                 # :66
+            if df == 0:
+                lo, hi = low_x, b.x - low_x
+            elif df == 1:
+                lo, hi = low_y, b.y - low_y
+            else:
+                lo, hi = low_z, b.z - low_z
+            assert lo <= hi
+            pos = rng.randint(lo, hi)                # :75
+            if df == 0:
+                new += [_Meta(pos, b.y, b.z, b.lx, b.ly, b.lz), _Meta(b.x - pos, b.y, b.z, b.lx + pos, b.ly, b.lz)]
+            elif df == 1:
+                new += [_Meta(b.x, pos, b.z, b.lx, b.ly, b.lz), _Meta(b.x, b.y - pos, b.z, b.lx, b.ly + pos, b.lz)]
+            else:
+                new += [_Meta(b.x, b.y, pos, b.lx, b.ly, b.lz), _Meta(b.x, b.y, b.z - pos, b.lx, b.ly, b.lz + pos)]
+            again = True
+        meta = new
+    plain = np.zeros((W, L), np.int32)
+    cands = []
+
+    def add_candidates():                            # :97-106
+        nonlocal meta
+        rest = []
+        for mb in meta:
+            if (plain[mb.lx:mb.lx + mb.x, mb.ly:mb.ly + mb.y] == mb.lz).sum() == mb.x * mb.y:
+                cands.append(mb)
+            else:
+                rest.append(mb)
+        meta = rest
+
+    add_candidates()
+    seq = []
+    while cands:                                     # :111-128
+        b = cands.pop(rng.randint(0, len(cands) - 1))
+        if rotation and np_rng.rand() >= 0.5:
+            seq.append((b.y, b.x, b.z))
+        else:
+            seq.append((b.x, b.y, b.z))
+        plain[b.lx:b.lx + b.x, b.ly:b.ly + b.y] += b.z
+        add_candidates()
+    return seq
+
+
+def cut1_pool(container_size, n, seed=0, box_range=(2, 2, 2, 5, 5, 5), rotation=False, T=None):
+    seqs = [cut1_sequence(container_size, box_range, random.Random(seed + k), rotation,
+                          np.random.RandomState(seed + k) if rotation else None) for k in range(n)]
+    return pad_pool(seqs, container_size, T)
+
+
 def rs_pool(container_size, n, length, seed=0, box_set=None):
     """RS sequences: items uniform over `box_set` (default {2..5}^3, acktr/arguments.py:122-128,
     envs/bpp0/binCreator.py:24-40).  Distribution parity only (the reference draws from the global

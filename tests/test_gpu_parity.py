@@ -241,3 +241,40 @@ def test_gpu_native_rollout_driver_matches_oracle(bpp, oracle):
         np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
         np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
         np.testing.assert_array_equal(env.state_numpy()["episode"], ref.state["episode"])
+
+
+def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
+    """The reference-shaped entry point: make_vec_envs(...) -> step() -> (obs device f32, reward CPU f32
+    [N,1], done numpy bool, infos of dicts) exactly like VecPyTorch (acktr/envs.py:170-193), replayed
+    against the golden rollout recorded from the reference stack."""
+    import types
+    import torch
+    g = load_golden("rollout_cut2_10_rot")
+    E = g["actions"].shape[1]
+    args = types.SimpleNamespace(container_size=(10, 10, 10), enable_rotation=True, data_type="cut2", box_size_set=None)
+    envs = bpp.make_vec_envs("Bpp-v0", 1, E, 1.0, "/tmp/unused", "cuda:0", False, args=args, pool=g["pool"])
+    assert envs.num_envs == E and envs.action_space.n == 200 and envs.observation_space.shape == (400,)
+    assert envs.action_space.__class__.__name__ == "Discrete"
+    obs = envs.reset()
+    assert obs.dtype == torch.float32 and obs.is_cuda and tuple(obs.shape) == (E, 400)
+    held = []
+    for t in range(40):
+        obs, reward, done, infos = envs.step(torch.from_numpy(g["actions"][t]).unsqueeze(1))
+        held.append(obs)
+        assert reward.dtype == torch.float32 and not reward.is_cuda and tuple(reward.shape) == (E, 1)
+        assert isinstance(done, np.ndarray) and done.dtype == bool and len(infos) == E
+        np.testing.assert_array_equal(obs.cpu().numpy(), g["obs"][t].astype(np.float32))
+        np.testing.assert_array_equal(reward.numpy()[:, 0], g["reward"][t])
+        np.testing.assert_array_equal(done, g["done"][t].astype(bool))
+        for e in range(E):
+            i = infos[e]
+            assert i["counter"] == g["counter"][t][e] and i["ratio"] == g["ratio"][t][e]
+            assert ("episode" in i.keys()) == bool(g["done"][t][e]) and "bad_transition" not in i.keys()
+            if done[e]:
+                assert i["episode"]["r"] == g["ep_r"][t][e] and i["episode"]["l"] == g["ep_l"][t][e]
+                assert i["mask"].shape == (200,)
+        m = bpp.get_rotation_mask(obs[0], (10, 10, 10))
+        np.testing.assert_array_equal(m, g["mask"][t][0])
+    # fresh_outputs (default of the factory): results of earlier steps are still intact
+    np.testing.assert_array_equal(held[5].cpu().numpy(), g["obs"][5].astype(np.float32))
+    envs.close()

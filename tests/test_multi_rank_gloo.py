@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: two `gloo` ranks, each owning a contiguous shard of global bin ids.  The shard
+arithmetic (shard_range, env_id_base/env_id_total sequence assignment) and the 32-byte statistics
+all-reduce (EpisodeStats.all_reduce) are the product code under test; the per-shard stepping is done by
+the oracle (there is no GPU here), and the concatenation of the shards must equal one global run."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bpp_amd
+
+SIZE, TOTAL, STEPS, SEED = (10, 10, 10), 52, 25, 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rollout(pool, lo, hi, total):
+    from oracle import oracle as orc
+    env = orc.OracleEnv(pool, SIZE, True, hi - lo, env_id_base=lo, env_id_total=total)
+    _, mask = env.reset()
+    obs = []
+    for t in range(STEPS):
+        a = orc.sample_feasible(mask, SEED, t, env_id_base=lo)
+        o = env.step(a)
+        mask = o["mask"]
+        obs.append(o["obs"])
+    return np.stack(obs), env.stats.sum(0)
+
+
+def _worker(rank, world, port, pool, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = bpp_amd.shard_range(TOTAL, rank, world)
+    obs, acc = _rollout(pool, lo, hi, TOTAL)
+    stats = bpp_amd.EpisodeStats("cpu")
+    stats.acc += torch.from_numpy(acc)
+    stats.all_reduce()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=obs, acc=stats.acc.numpy(), lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_equal_one_global_run(tmp_path):
+    pool = bpp_amd.sequences.cut2_pool(SIZE, 23, seed=2)
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), pool, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert [(int(p["lo"]), int(p["hi"])) for p in parts] == [(0, 26), (26, 52)]
+    g_obs, g_acc = _rollout(pool, 0, TOTAL, TOTAL)
+    np.testing.assert_array_equal(np.concatenate([p["obs"] for p in parts], axis=1), g_obs)
+    for p in parts:                                   # every rank holds the global sums after the all-reduce
+        np.testing.assert_allclose(p["acc"], g_acc, rtol=1e-12)
+    assert g_acc[3] > 0
+
+
+def test_shard_range_covers_everything_once():
+    for total, world in ((65536 * 8, 8), (10, 3), (7, 8), (1, 1)):
+        spans = [bpp_amd.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_episode_stats_all_reduce_is_noop_without_process_group():
+    s = bpp_amd.EpisodeStats("cpu")
+    s.acc += torch.tensor([4.0, 2.0, 8.0, 2.0], dtype=torch.float64)
+    assert s.all_reduce().summary() == {"episodes": 2, "mean_return": 2.0, "mean_ratio": 1.0, "mean_length": 4.0}

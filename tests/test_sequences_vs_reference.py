@@ -1,0 +1,49 @@
+"""Build-container only (needs /root/reference): the host-side item generators reproduce the
+reference's creators exactly when fed the same Python RNG stream."""
+import contextlib
+import io
+import random
+
+import numpy as np
+import pytest
+
+from bpp_amd import sequences
+from oracle import ref_shims
+
+pytestmark = pytest.mark.skipif(not ref_shims.available(), reason="reference tree not present")
+
+
+@pytest.mark.parametrize("size,n", [((10, 10, 10), 60), ((20, 20, 20), 8), ((20, 20, 10), 10)])
+def test_cut2_generator_is_rng_exact(size, n):
+    ref_shims.install()
+    from envs.bpp0.mdCreator import MDlayerBoxCreator
+    with contextlib.redirect_stdout(io.StringIO()):
+        cr = MDlayerBoxCreator(size, [2, 5])
+        for s in range(n):
+            random.seed(1000 + s)
+            cr.reset()
+            ref = [tuple(b) for b in cr.box_set[:-1]]
+            assert sequences.cut2_sequence(size, (2, 5), random.Random(1000 + s)) == ref
+
+
+@pytest.mark.parametrize("size,rot,n", [((10, 10, 10), False, 40), ((10, 10, 10), True, 20), ((20, 20, 20), False, 4)])
+def test_cut1_generator_is_rng_exact(size, rot, n):
+    ref_shims.install()
+    from envs.bpp0.cutCreator import CuttingBoxCreator
+    rng = (2, 2, 2, 5, 5, 5)
+    for s in range(n):
+        random.seed(77 + s)
+        np.random.seed(77 + s)
+        cr = CuttingBoxCreator(size, list(rng), rot)     # __init__ cuts once ...
+        random.seed(77 + s)
+        np.random.seed(77 + s)
+        cr.reset()                                        # ... reset() cuts again from the same stream
+        ref = []
+        while True:
+            cr.generate_box_size()
+            if tuple(cr.box_list[-1]) == tuple(size) and len(cr.candidates) == 0:
+                break
+            ref.append(tuple(int(v) for v in cr.box_list[-1]))
+        mine = sequences.cut1_sequence(size, rng, random.Random(77 + s), rot, np.random.RandomState(77 + s))
+        assert mine == ref
+        assert sum(x * y * z for x, y, z in mine) == size[0] * size[1] * size[2]
