@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 1
+#define BPP_ABI_VERSION 2
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -71,7 +71,9 @@ typedef struct bpp_batch {
     int64_t env_id_total;  /* bins in the whole job; episode k of global bin g plays sequence
                               (g + k * env_id_total) mod P, independent of the GPU count           */
     const uint8_t *seq_pool; /* [P][T][4] = (x, y, z, 0) item sizes                                */
-    int32_t *hmap;         /* [E][W*L] Space.plain, row-major idx = lx*L + ly,
+    uint8_t *hmap;         /* [E][W*L] Space.plain held as BYTES (heights <= H <= 255; the reference's
+                              int32 only exists at the contract edge: obs plane 0 carries the same
+                              values as float32), row-major idx = lx*L + ly,
                               envs/bpp0/space.py:22,153-156                                        */
     bpp_env_state *state;  /* [E]                                                                  */
     double *stats;         /* NULL, or [BPP_STATS_SLOTS][4] episode statistics accumulated by bpp_step

@@ -48,13 +48,15 @@ struct Params {
     int32_t lds_per_wave;  // bytes
     int32_t off_mk, off_rec, off_ori, off_P;
     int32_t epw_shift;     // epw == 1 << epw_shift on the fast path
+    int32_t obs_order;     // 1: odd waves write the observation after the mask phases
+    int32_t xcd_remap;     // 1: XCD-aware block -> bins mapping
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
     double binvol;
     const uint32_t *pool;  // [P][T] packed x | y<<8 | z<<16
     // state
-    int32_t *hmap;
+    uint8_t *hmap;   // [E][A] bytes
     bpp_env_state *state;
     double *stats;  // [BPP_STATS_SLOTS][4] or nullptr
     const int64_t *actions;
@@ -80,6 +82,17 @@ struct __attribute__((aligned(16))) BinRec {
     uint32_t flags;  // bit0 placed, bit1 reset (zero the map), bits 8.. new top height
     uint32_t any;    // set to 1 by any feasible candidate
 };
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).
+// Give every XCD one contiguous eighth of the bins so that cache lines shared by neighbouring waves
+// (the small per-bin outputs, the byte heightmaps) are completed inside ONE L2 instead of being written
+// back as partial lines from several.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_block(int remap) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    if (!remap || nb < 16) return b;
+    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
 
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * (blockDim.x >> 6) + wid) * p.epw;
+    const int e0 = (xcd_block(p.xcd_remap) * (blockDim.x >> 6) + wid) * p.epw;
     if (e0 >= p.E) return;  // no block-level barrier is ever used, a whole wave may leave
     const int nenv = min(p.epw, p.E - e0);
     const int A = p.A, L = p.L, M = p.M;
@@ -165,8 +178,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
     constexpr int GW = VEC ? 4 : 1;          // cells handled per lane per access
 
     // ---- phase 1: stage this wave's heightmaps into LDS as bytes -------------------------------
-    if (MODE == kStep || MODE == kMaskHmap) {
-        const int32_t *gh = (MODE == kStep ? p.hmap : p.hmap_in) + (size_t)e0 * A;
+    if (MODE == kStep) {
+        const uint8_t *gh = p.hmap + (size_t)e0 * A;
+        if (VEC) {
+            for (int q = lane; q < ncell / 4; q += kWave) ((uint32_t *)hm)[q] = ((const uint32_t *)gh)[q];
+        } else {
+            for (int c = lane; c < ncell; c += kWave) hm[c] = gh[c];
+        }
+    } else if (MODE == kMaskHmap) {
+        const int32_t *gh = p.hmap_in + (size_t)e0 * A;
         if (VEC) {
             for (int q = lane; q < ncell / 4; q += kWave) {
                 int4 v = ((const int4 *)gh)[q];
@@ -331,10 +351,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             }
             wave_sync();
         }
-        // ---- phase 3b: stream out the int32 heightmap and the float32 observation ---------------
+        // ---- phase 3b: stream out the byte heightmap (state) and the float32 observation -----------
         // bin3D.py:49-66: planes [hmap, x, y, z]; float32 at the VecEnv buffer (shmem_vec_env.py:42-43)
         {
-            int32_t *gh = p.hmap + (size_t)e0 * A;
+            uint8_t *gh = p.hmap + (size_t)e0 * A;
             float *go = p.obs + (size_t)e0 * 4 * A;
             const int per_plane = A / GW;
             for (int g = lane; g < nenv * 4 * per_plane; g += kWave) {
@@ -344,12 +364,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 if (plane == 0) {
                     if (VEC) {
                         const uint32_t v = ((uint32_t *)hm)[el * per_plane + k];
-                        const int4 iv = make_int4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
-                        ((int4 *)gh)[el * per_plane + k] = iv;
-                        ((float4 *)go)[g] = make_float4((float)iv.x, (float)iv.y, (float)iv.z, (float)iv.w);
+                        ((uint32_t *)gh)[el * per_plane + k] = v;
+                        ((float4 *)go)[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                        (float)(v >> 24));
                     } else {
                         const int v = hm[el * A + k];
-                        gh[el * A + k] = v;
+                        gh[el * A + k] = (uint8_t)v;
                         go[g] = (float)v;
                     }
                 } else {
@@ -508,7 +528,7 @@ __device__ __forceinline__ OriRec make_ori(int x, int y, int z, int H) {
     o.a = (uint32_t)x | ((uint32_t)y << 8) | (hz1 << 16) | (big << 25) | (valid << 26);
     o.b = (uint32_t)(19 * area / 20 + 1) | ((uint32_t)(17 * area / 20 + 1) << 16);
     o.c = (uint32_t)(area / 2 + 1) | ((uint32_t)((W - x) & 255) << 16) | ((uint32_t)((L - y) & 255) << 24);
-    o.d = 0;
+    o.d = (65536u + (uint32_t)(L - y + 1) - 1u) / (uint32_t)max(L - y + 1, 1);  // ceil(2^16 / nj): t / nj == (t * d) >> 16 for t < 1024
     return o;
 }
 
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * (blockDim.x >> 6) + wid) * p.epw;
+    const int e0 = (xcd_block(p.xcd_remap) * (blockDim.x >> 6) + wid) * p.epw;
     if (e0 >= p.E) return;
     const int nenv = min(p.epw, p.E - e0);
     unsigned char *wb = smem + wid * p.lds_per_wave;
@@ -532,8 +552,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
 
     // ---- phase 1: stage heightmaps as bytes ------------------------------------------------------
-    if (MODE == kStep || MODE == kMaskHmap) {
-        const int4 *gh = (const int4 *)((MODE == kStep ? p.hmap : p.hmap_in) + (size_t)e0 * A);
+    if (MODE == kStep) {
+        const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)e0 * A);
+        for (int q = lane; q < nenv * A4; q += kWave) hm32[q] = gh[q];
+    } else if (MODE == kMaskHmap) {
+        const int4 *gh = (const int4 *)(p.hmap_in + (size_t)e0 * A);
         for (int q = lane; q < nenv * A4; q += kWave) {
             const int4 v = gh[q];
             hm32[q] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) | (min((uint32_t)v.z, 255u) << 16) |
@@ -686,6 +709,25 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     }
     wave_sync();
 
+    const bool late_obs = (MODE == kStep) && (p.obs_order != 0) && ((wid & 1) != 0);
+    auto write_obs = [&]() {
+        uint32_t *gh = (uint32_t *)(p.hmap + (size_t)e0 * A);
+        float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
+        for (int q = lane; q < nenv * A4; q += kWave) {
+            const int el = q / A4;
+            const uint32_t v = hm32[q];
+            gh[q] = v;
+            go[q + el * (3 * A4)] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                (float)(v >> 24));
+        }
+        for (int g = lane; g < nenv * 3 * A4; g += kWave) {
+            const int el = g / (3 * A4);
+            const int r3 = g - el * (3 * A4);
+            const float f = (float)((rec[el].item >> (8 * (r3 / A4))) & 255u);
+            go[g + (el + 1) * A4] = make_float4(f, f, f, f);
+        }
+    };
+
     if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
         if (MODE == kStep) {
             // ---- phase 3a: finished bins restart from an empty map --------------------------------
@@ -694,21 +736,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             wave_sync();
         }
         // ---- phase 3b: int32 heightmap + float32 observation out (bin3D.py:49-66) -----------------
-        int4 *gh = (int4 *)(p.hmap + (size_t)e0 * A);
-        float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
-        for (int q = lane; q < nenv * A4; q += kWave) {
-            const int el = q / A4;
-            const uint32_t v = hm32[q];
-            const int4 iv = make_int4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
-            gh[q] = iv;
-            go[q + el * (3 * A4)] = make_float4((float)iv.x, (float)iv.y, (float)iv.z, (float)iv.w);
-        }
-        for (int g = lane; g < nenv * 3 * A4; g += kWave) {
-            const int el = g / (3 * A4);
-            const int r3 = g - el * (3 * A4);
-            const float f = (float)((rec[el].item >> (8 * (r3 / A4))) & 255u);
-            go[g + (el + 1) * A4] = make_float4(f, f, f, f);
-        }
+        // Odd waves emit it AFTER the mask phases instead, so that on every SIMD store-heavy and
+        // VALU-heavy phases of co-resident waves interleave instead of all waves streaming at once.
+        if (!late_obs || p.mask == nullptr) write_obs();
         if (p.mask == nullptr) return;
     }
 
@@ -759,41 +789,54 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     }
 
     // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94) ----------------
-    for (int c = lane; c < nenv * M; c += kWave) {
-        const int el = c / M;
-        const int r = c - el * M;
-        const int rot = (ROT && r >= A) ? 1 : 0;                       // utils.py:81-89: second half
-        const int cell = r - rot * A;
-        const int i = cell / L, j = cell - i * L;
-        const OriRec o = ori[el * 2 + rot];
-        const int x = o.a & 255u, y = (o.a >> 8) & 255u;
-        const int imax = (o.c >> 16) & 255u, jmax = o.c >> 24;
-        bool f = false;
-        if ((o.a & (1u << 26)) && i <= imax && j <= jmax) {            // utils.py:54-55 loop ranges
-            const Ent<K> *Pb = P + el * PN + i * PW + j;
-            int mh, ma;
-            if (!(o.a & (1u << 25))) {
-                const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
-                Ent<K> h;
+    // Bin-uniform evaluation: the wave walks its bins (and orientations) one after the other, so the
+    // item constants live in scalar registers, and only the (W-x+1)*(L-y+1) in-range candidates
+    // (utils.py:54-55 loop ranges) are enumerated -- lane t <-> (i, j) = (t / nj, t % nj).
+    for (int g = lane; g < nenv * (M / 4); g += kWave) ((uint32_t *)mk)[g] = 0u;
+    wave_sync();
+    for (int el = 0; el < nenv; ++el) {
+        unsigned long long any = 0ull;
+        const Ent<K> *Pe = P + el * PN;
+        const uint8_t *he = hm + el * A;
+        uint8_t *me = mk + el * M;
 #pragma unroll
-                for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
-                top_of<K>(h, mh, ma);
-            } else {
-                window_top<K>(P + el * PN, PW, i, j, x, y, mh, ma);
-            }
-            const uint8_t *hb = hm + el * A + cell;
+        for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
+            const OriRec ov = ori[el * 2 + rot];
+            const uint32_t oa = __builtin_amdgcn_readfirstlane(ov.a), ob = __builtin_amdgcn_readfirstlane(ov.b),
+                           oc = __builtin_amdgcn_readfirstlane(ov.c), od = __builtin_amdgcn_readfirstlane(ov.d);
+            if (!(oa & (1u << 26))) continue;                          // item does not fit at all
+            const int x = oa & 255u, y = (oa >> 8) & 255u, hz1 = (oa >> 16) & 511u;
+            const bool big = (oa >> 25) & 1u;
+            const int nj = (int)(oc >> 24) + 1, nv = ((int)((oc >> 16) & 255u) + 1) * nj;
+            const int t95 = ob & 0xffffu, t85 = ob >> 16, t50 = oc & 0xffffu;
             const int o10 = (x - 1) * L, o01 = y - 1;
-            const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
-            const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
-            const int thr = cnt == 4 ? (int)(o.c & 0xffffu) : (cnt == 3 ? (int)(o.b >> 16) : (int)(o.b & 0xffffu));
-            f = (mh < (int)((o.a >> 16) & 511u)) && (ma >= thr);       // utils.py:20-33
-            if (p.rule == BPP_RULE_SPACE) {                            // space.py:122-125: sc >= 3
-                const int rm = max(max(r00, r10), max(r01, r11));
-                f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+            for (int t = lane; t < nv; t += kWave) {
+                const int i = (int)(((uint32_t)t * od) >> 16), j = t - i * nj;
+                const Ent<K> *Pb = Pe + i * PW + j;
+                int mh, ma;
+                if (!big) {
+                    const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                    Ent<K> h;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
+                    top_of<K>(h, mh, ma);
+                } else {
+                    window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                }
+                const uint8_t *hb = he + i * L + j;
+                const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+                const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
+                const int thr = cnt == 4 ? t50 : (cnt == 3 ? t85 : t95);
+                bool f = (mh < hz1) && (ma >= thr);                    // utils.py:20-33
+                if (p.rule == BPP_RULE_SPACE) {                        // space.py:122-125: sc >= 3
+                    const int rm = max(max(r00, r10), max(r01, r11));
+                    f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+                }
+                me[rot * A + i * L + j] = f ? 1 : 0;
+                any |= __ballot(f);
             }
         }
-        mk[c] = f ? 1 : 0;
-        if (f) rec[el].any = 1u;
+        if (any != 0ull && lane == 0) rec[el].any = 1u;
     }
     wave_sync();
 
@@ -805,6 +848,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
         }
     }
+    if (late_obs) write_obs();
 }
 
 // Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
@@ -1015,6 +1059,10 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
         epw = 1 << sh;
         p.epw_shift = sh;
     }
+    const char *oo = getenv("BPP_OBS_ORDER");
+    p.obs_order = oo ? atoi(oo) : 0;
+    const char *xr = getenv("BPP_XCD");
+    p.xcd_remap = xr ? atoi(xr) : 1;
     p.epw = epw;
     p.off_mk = (epw * p.A + 15) & ~15;
     p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
@@ -1068,7 +1116,7 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     if (!out || !out->obs) return fail(BPP_E_BADARG, "bpp_step_out: NULL obs");
     if (need_all && (!out->reward || !out->done || !out->counter || !out->ratio || !out->ep_ret || !out->ep_len))
         return fail(BPP_E_BADARG, "bpp_step_out: NULL pointer");
-    if (!aligned16(b->hmap) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
+    if (((uintptr_t)b->hmap & 3u) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
         ((uintptr_t)b->seq_pool & 3u))
         return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
     Params &p = l.p;

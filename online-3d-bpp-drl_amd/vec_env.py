@@ -131,7 +131,7 @@ class BppVecEnv(object):
         dev = self.device
         with torch.cuda.device(dev):
             self.pool = torch.from_numpy(self.pool_host).to(dev)
-            self.hmap = torch.zeros((self.E, self.A), dtype=torch.int32, device=dev)
+            self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
             self.state = torch.zeros((self.E, 8), dtype=torch.int32, device=dev)  # bpp_env_state[E], 32 B each
             # episode statistics accumulated inside the step kernel: [slots][return, ratio, length, count]
             self.stats_slots = torch.zeros((_lib.STATS_SLOTS, 4), dtype=torch.float64, device=dev)

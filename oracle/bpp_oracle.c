@@ -143,7 +143,8 @@ static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item
 /* PackingGame.cur_observation (envs/bpp0/bin3D.py:61-66) as float32 (shmem_vec_env.py:42-43) + mask. */
 static void write_obs_mask(const bpp_batch *b, int e, const int item[3], const bpp_step_out *out) {
     int A = b->W * b->L, M = A * (1 + b->rotation);
-    const int32_t *plain = b->hmap + (size_t)e * A;
+    int32_t plain[A];
+    for (int k = 0; k < A; ++k) plain[k] = b->hmap[(size_t)e * A + k];
     float *o = out->obs + (size_t)e * 4 * A;
     for (int k = 0; k < A; ++k) {
         o[k] = (float)plain[k];
@@ -159,7 +160,7 @@ static void write_obs_mask(const bpp_batch *b, int e, const int item[3], const b
 /* PackingGame.reset (bin3D.py:55-59) + Monitor.reset_state (bench/monitor.py:45-49). */
 static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
     int A = b->W * b->L;
-    memset(b->hmap + (size_t)e * A, 0, sizeof(int32_t) * A); /* space.py:22 */
+    memset(b->hmap + (size_t)e * A, 0, (size_t)A); /* space.py:22 */
     s->cursor = 0;
     s->n_boxes = 0;
     s->vol_sum = 0;
@@ -195,7 +196,9 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
     const int W = b->W, L = b->L, H = b->H, A = W * L;
     for (int e = 0; e < b->num_envs; ++e) {
         bpp_env_state *s = b->state + e;
-        int32_t *plain = b->hmap + (size_t)e * A;
+        uint8_t *bytes = b->hmap + (size_t)e * A;      /* state is kept as bytes; work on an int32 copy */
+        int32_t plain[A];
+        for (int k = 0; k < A; ++k) plain[k] = bytes[k];
         int item[3];
         next_box(b, e, s, item);
         /* bin3D.py:96-105 */
@@ -229,7 +232,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
                     if (plain[i * L + j] > max_h) max_h = plain[i * L + j];
             if (new_h + z > max_h) max_h = new_h + z;
             for (int i = lx; i < lx + x; ++i)
-                for (int j = ly; j < ly + y; ++j) plain[i * L + j] = max_h;
+                for (int j = ly; j < ly + y; ++j) bytes[i * L + j] = (uint8_t)max_h;
             s->n_boxes += 1;
             s->vol_sum += x * y * z;
             /* bin3D.py:44-46,114,121: float64 (vol / binvol) * 10 */

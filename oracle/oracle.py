@@ -85,7 +85,7 @@ class OracleEnv(object):
         self.rotation = int(bool(rotation))
         self.M = self.A * (1 + self.rotation)
         self.E = int(num_envs)
-        self.hmap = np.zeros((self.E, self.A), np.int32)
+        self.hmap = np.zeros((self.E, self.A), np.uint8)
         self.state = np.zeros(self.E, STATE_DTYPE)
         self.out = dict(obs=np.zeros((self.E, 4 * self.A), np.float32), mask=np.zeros((self.E, self.M), np.float32),
                         reward=np.zeros(self.E, np.float32), done=np.zeros(self.E, np.uint8),

@@ -175,7 +175,7 @@ def test_gpu_full_size_properties_and_slices(bpp, oracle, kernel_path, size, rot
         done = r.done.bool()
         o4 = r.obs.view(E, 4, A)
         # plane 0 is the int32 heightmap, planes 1-3 are constant = next item
-        assert torch.equal(o4[:, 0], env.hmap.float())
+        assert torch.equal(o4[:, 0], env.hmap.float())   # uint8 state == float32 plane 0
         assert bool((o4[:, 1:] == o4[:, 1:, :1]).all())
         assert int(env.hmap.max()) <= H and int(env.hmap.min()) >= 0
         # masks are 0/1, never all-zero
