@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 2
+#define BPP_ABI_VERSION 3
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -44,8 +44,9 @@ extern "C" {
 #define BPP_RESET_INIT    0 /* first reset: episode index 0                                        */
 #define BPP_RESET_ADVANCE 1 /* later VecEnv.reset(): every bin abandons its episode, next sequence */
 
-/* Per-bin scalar state, 32 bytes, array-of-structs so one bin's record is two 16-byte accesses.
- * Replaces the Python objects hanging off one PackingGame + its bench.Monitor wrapper. */
+/* Per-bin scalar state, 48 bytes, array-of-structs so one bin's record is three 16-byte accesses.
+ * Replaces the Python objects hanging off one PackingGame + its bench.Monitor wrapper.  The last four
+ * words cache pool entries (packed x | y<<8 | z<<16) so that a step needs no dependent pool lookup. */
 typedef struct bpp_env_state {
     int32_t cursor;   /* index of `next_box` in the current sequence: BoxCreator FIFO head,
                          envs/bpp0/binCreator.py:15-22, envs/bpp0/bin3D.py:68-70                   */
@@ -55,6 +56,10 @@ typedef struct bpp_env_state {
     double  ep_ret;   /* bench.Monitor running sum(self.rewards), baselines/bench/monitor.py:58-62 */
     int32_t ep_len;   /* bench.Monitor len(self.rewards), baselines/bench/monitor.py:63            */
     int32_t seq;      /* pool row this episode plays = (global bin id + episode*env_id_total) mod P */
+    uint32_t item_cur;   /* pool[seq][min(cursor, T-1)]: BoxCreator.preview(1)[0], binCreator.py:15-18  */
+    uint32_t item_next;  /* pool[seq][min(cursor+1, T-1)]: the item shown after a successful placement  */
+    uint32_t item_reset; /* pool[next episode's row][0]: the item shown after a failed placement        */
+    uint32_t pad;
 } bpp_env_state;
 
 /* One shard of bins living on one device.  Replaces N x (PackingGame + Space + BoxCreator +

@@ -13,7 +13,7 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 LIB = os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256

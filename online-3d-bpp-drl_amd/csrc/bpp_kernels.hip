@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
+constexpr int kMaxFastWavesPerBlock = 16;  // fast path: wave 0 serves wpb * epw <= 64 bins
 constexpr int kMaxArea = 1024;  // W*L
 constexpr int kMaxDim = 255;    // W, L, H and item sizes are bytes
 
@@ -50,6 +51,7 @@ struct Params {
     int32_t epw_shift;     // epw == 1 << epw_shift on the fast path
     int32_t obs_order;     // 1: odd waves write the observation after the mask phases
     int32_t xcd_remap;     // 1: XCD-aware block -> bins mapping
+    int32_t ablate;        // profiling aid (BPP_ABLATE bit mask): skip a phase to read its cost; results are then wrong
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
@@ -233,15 +235,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         if (MODE == kStep) {
             bpp_env_state st = p.state[e];
             const int64_t act = p.actions[e];
-            // BoxCreator.preview(1)[0] (binCreator.py:15-18): current item, the one after it, and
-            // the first item of the next episode's sequence are fetched together.
+            // BoxCreator.preview(1)[0] (binCreator.py:15-18): the current item, the one after it and the
+            // first item of the next episode are cached in the state record; the entries the NEXT step
+            // will need are fetched here, speculatively for both outcomes, off the critical path.
             const int T = p.T;
             int seq_n = st.seq + p.seq_stride;
             seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
-            const uint32_t *srow = p.pool + (size_t)st.seq * T;
-            const uint32_t it_cur = srow[min(st.cursor, T - 1)];
-            const uint32_t it_nxt = srow[min(st.cursor + 1, T - 1)];
-            const uint32_t it_rst = p.pool[(size_t)seq_n * T];
+            int seq_nn = seq_n + p.seq_stride;
+            seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
+            const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
+            const uint32_t sp_ok = p.pool[(size_t)st.seq * T + min(st.cursor + 2, T - 1)];
+            const uint32_t sp_f1 = p.pool[(size_t)seq_n * T + min(1, T - 1)];
+            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             // bin3D.py:96-105: rotated iff idx > area (strict)
             int64_t idx = act;
@@ -279,6 +284,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             fin_len = st.ep_len;
             if (ok) {
                 st.cursor += 1;  // bin3D.py:116-117
+                st.item_cur = it_nxt;
+                st.item_next = sp_ok;
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
@@ -290,6 +297,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 st.vol_sum = 0;
                 st.ep_ret = 0.0;
                 st.ep_len = 0;
+                st.item_cur = it_rst;
+                st.item_next = sp_f1;
+                st.item_reset = sp_f2;
                 r.item = it_rst;
                 r.flags = 2u;
             }
@@ -310,8 +320,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.vol_sum = 0;
             st.ep_ret = 0.0;
             st.ep_len = 0;
+            int sn = st.seq + p.seq_stride;
+            sn = sn >= p.P ? sn - p.P : sn;
+            st.item_cur = p.pool[(size_t)st.seq * p.T];
+            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
+            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.pad = 0;
             p.state[e] = st;
-            r.item = p.pool[(size_t)st.seq * p.T];
+            r.item = st.item_cur;
             r.flags = 2u;
         } else if (MODE == kMaskObs) {
             // acktr/utils.py:43-45: x, y, z = int(plane[k][0])
@@ -533,15 +549,16 @@ __device__ __forceinline__ OriRec make_ori(int x, int y, int z, int H) {
 }
 
 template <int W, int L, int K, bool ROT, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const Params p) {
+__global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel(const Params p) {
     constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, PW = L + 1, PN = (W + 1) * (L + 1);
     static_assert(A % 4 == 0, "fast path needs W*L % 4 == 0");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
-    const int e0 = (xcd_block(p.xcd_remap) * (blockDim.x >> 6) + wid) * p.epw;
-    if (e0 >= p.E) return;
-    const int nenv = min(p.epw, p.E - e0);
+    const int wpb = blockDim.x >> 6;
+    const int blk_e0 = xcd_block(p.xcd_remap) * wpb * p.epw;       // first bin of this workgroup
+    const int e0 = blk_e0 + wid * p.epw;                           // first bin of this wave
+    const int nenv = max(0, min(p.epw, p.E - e0));                 // block barriers below: no early return
     unsigned char *wb = smem + wid * p.lds_per_wave;
     uint8_t *hm = wb;
     uint32_t *hm32 = (uint32_t *)wb;
@@ -551,10 +568,21 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     Ent<K> *P = (Ent<K> *)(wb + p.off_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
 
+    if (p.ablate & 16) return;
+    // The deciding wave (wave 0) issues its per-bin loads first, so their latency overlaps the staging.
+    const int dec_nb = max(0, min(wpb * p.epw, p.E - blk_e0));
+    const int dec_e = blk_e0 + (lane < dec_nb ? lane : 0);
+    bpp_env_state st0;
+    int64_t act0 = 0;
+    if (MODE == kStep && wid == 0 && !(p.ablate & 32)) {
+        st0 = p.state[dec_e];
+        act0 = p.actions[dec_e];
+    }
+
     // ---- phase 1: stage heightmaps as bytes ------------------------------------------------------
     if (MODE == kStep) {
         const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)e0 * A);
-        for (int q = lane; q < nenv * A4; q += kWave) hm32[q] = gh[q];
+        for (int q = lane; q < ((p.ablate & 64) ? 0 : nenv * A4); q += kWave) hm32[q] = gh[q];
     } else if (MODE == kMaskHmap) {
         const int4 *gh = (const int4 *)(p.hmap_in + (size_t)e0 * A);
         for (int q = lane; q < nenv * A4; q += kWave) {
@@ -572,33 +600,41 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     } else {
         for (int q = lane; q < nenv * A4; q += kWave) hm32[q] = 0u;  // space.py:22
     }
-    wave_sync();
+    __syncthreads();  // wave 0 reads the other waves' tiles below
 
-    // ---- phase 2: per-bin scalar work, one sub-group of G = 64/epw lanes per bin ------------------
-    // Every lane of a sub-group carries the bin's scalars redundantly; the placement window is split
-    // by rows over the sub-group and the (max, count) pairs are merged with a butterfly.  Shuffles are
-    // executed by the whole wave (no divergence around them).
-    {
-        const int G = kWave >> p.epw_shift;
-        const int el = lane >> (6 - p.epw_shift);  // bin within the wave
-        const int sl = lane & (G - 1);             // lane within the sub-group
-        const bool active = el < nenv;
-        const int e = e0 + (active ? el : 0);
+    // ---- phase 2: per-bin scalar work, lane-per-bin, done by ONE wave for the whole workgroup ------
+    // A workgroup owns wpb * epw (<= 64) consecutive bins.  Wave 0 carries one bin per lane through the
+    // scalar chain (state, action, items, placement rule, reward, Monitor, next item) and leaves a
+    // record per bin in the owning wave's LDS area; the other waves wait at the barrier.  (Executing
+    // this chain in every wave for only `epw` bins cost 45 % of the kernel.)
+    if (wid == 0 && !(p.ablate & 32)) {
+        const bool active = lane < dec_nb;
+        const int e = dec_e;
+        const int ow = lane >> p.epw_shift, oel = lane & (p.epw - 1);  // owning wave, bin within it
+        unsigned char *ob = smem + ow * p.lds_per_wave;
+        const uint8_t *ohm = ob + oel * A;
         BinRec r;
         r.item = 0;
         r.place = 0;
         r.flags = 0;
         r.any = 0;
+        bool fin = false;
+        double fin_ret = 0.0, fin_ratio = 0.0;
+        int fin_len = 0;
         if (MODE == kStep) {
-            bpp_env_state st = p.state[e];
-            const int64_t act = p.actions[e];
+            bpp_env_state st = st0;                                    // loaded before the tile was staged
+            const int64_t act = act0;
+            // binCreator.py:15-18: current / next / first-of-next-episode items come from the state record;
+            // the pool entries the NEXT step needs are fetched speculatively for both outcomes.
             const int T = p.T;
             int seq_n = st.seq + p.seq_stride;
             seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
-            const uint32_t *srow = p.pool + (size_t)st.seq * T;
-            const uint32_t it_cur = srow[min(st.cursor, T - 1)];       // binCreator.py:15-18
-            const uint32_t it_nxt = srow[min(st.cursor + 1, T - 1)];
-            const uint32_t it_rst = p.pool[(size_t)seq_n * T];
+            int seq_nn = seq_n + p.seq_stride;
+            seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
+            const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
+            const uint32_t sp_ok = p.pool[(size_t)st.seq * T + min(st.cursor + 2, T - 1)];
+            const uint32_t sp_f1 = p.pool[(size_t)seq_n * T + min(1, T - 1)];
+            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             int64_t idx = act;                                         // bin3D.py:96-105
             const bool flag = ROT && idx > A;
@@ -611,25 +647,33 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
                 ly = (int)idx - lx * L;
                 ok = (lx + x <= W) && (ly + y <= L);                   // space.py:112-115
             }
-            uint8_t *hb = hm + el * A + lx * L + ly;
-            int mh = 0, ma = 0;                                        // space.py:127-129, rows split
-            if (ok)
-                for (int a = sl; a < x; a += G) {
-                    const uint8_t *row = hb + a * L;
-                    for (int b = 0; b < y; ++b) {
-                        const int v = row[b];
-                        ma = v > mh ? 1 : ma + (v == mh);
-                        mh = max(mh, v);
-                    }
-                }
-            for (int d = 1; d < G; d <<= 1) {
-                const int m2 = __shfl_xor(mh, d, kWave), c2 = __shfl_xor(ma, d, kWave);
-                const int nm = max(mh, m2);
-                ma = (mh == nm ? ma : 0) + (m2 == nm ? c2 : 0);
-                mh = nm;
-            }
             int top = 0;
             if (ok) {
+                const uint8_t *hb = ohm + lx * L + ly;
+                int mh = 0, ma = 0;                                    // space.py:127-129
+                if (x <= 5 && y <= 5) {
+                    // common item sizes: 25 predicated independent LDS reads instead of a divergent loop
+                    int v[5][5];
+#pragma unroll
+                    for (int a = 0; a < 5; ++a)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) v[a][b] = (a < x && b < y) ? (int)hb[a * L + b] : -1;
+#pragma unroll
+                    for (int a = 0; a < 5; ++a)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) mh = max(mh, v[a][b]);
+#pragma unroll
+                    for (int a = 0; a < 5; ++a)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) ma += (v[a][b] == mh);
+                } else {
+                    for (int a = 0; a < x; ++a)
+                        for (int b = 0; b < y; ++b) {
+                            const int v = hb[a * L + b];
+                            ma = v > mh ? 1 : ma + (v == mh);
+                            mh = max(mh, v);
+                        }
+                }
                 const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
                 const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125
                 Win w;
@@ -646,9 +690,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             st.vol_sum += ok ? vol : 0;
             st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
             st.ep_len += 1;
-            const bool writer = active && sl == 0;
             const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
-            if (writer) {
+            if (active) {
                 p.reward[e] = (float)rew;                              // acktr/envs.py:192
                 p.done[e] = ok ? 0 : 1;
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
@@ -656,13 +699,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
                 p.ep_ret[e] = st.ep_ret;
                 p.ep_len[e] = st.ep_len;
             }
-            if (p.stats) wave_episode_stats(p.stats, e0 >> p.epw_shift, writer && !ok, st.ep_ret, ratio, st.ep_len);
+            fin = active && !ok;
+            fin_ret = st.ep_ret;
+            fin_ratio = ratio;
+            fin_len = st.ep_len;
             if (ok) {
                 st.cursor += 1;                                        // bin3D.py:116-117
+                st.item_cur = it_nxt;
+                st.item_next = sp_ok;
                 r.item = it_nxt;
-                r.flags = 1u;
-                for (int a = sl; a < x; a += G)                        // space.py:36-46: window := max_h + z
-                    for (int b = 0; b < y; ++b) hb[a * L + b] = (uint8_t)top;
+                r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+                r.flags = 1u | ((uint32_t)top << 8);
             } else {                                                   // shmem_vec_env.py:128-129
                 st.episode += 1;
                 st.seq = seq_n;
@@ -671,10 +718,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
                 st.vol_sum = 0;
                 st.ep_ret = 0.0;
                 st.ep_len = 0;
+                st.item_cur = it_rst;
+                st.item_next = sp_f1;
+                st.item_reset = sp_f2;
                 r.item = it_rst;
                 r.flags = 2u;
             }
-            if (writer) p.state[e] = st;
+            if (active) p.state[e] = st;
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -691,8 +741,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             st.vol_sum = 0;
             st.ep_ret = 0.0;
             st.ep_len = 0;
-            if (active && sl == 0) p.state[e] = st;
-            r.item = p.pool[(size_t)st.seq * p.T];
+            int sn = st.seq + p.seq_stride;
+            sn = sn >= p.P ? sn - p.P : sn;
+            st.item_cur = p.pool[(size_t)st.seq * p.T];
+            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
+            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.pad = 0;
+            if (active) p.state[e] = st;
+            r.item = st.item_cur;
         } else if (MODE == kMaskObs) {
             const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
             r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
@@ -700,14 +756,35 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
             const int32_t *it = p.items_in + (size_t)e * 3;
             r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
         }
-        if (active && sl == 0) {
-            rec[el] = r;
+        if (MODE == kStep && p.stats)
+            wave_episode_stats(p.stats, blockIdx.x, fin, fin_ret, fin_ratio, fin_len);
+        if (active) {
+            ((BinRec *)(ob + p.off_rec))[oel] = r;
+            OriRec *oo = (OriRec *)(ob + p.off_ori) + oel * 2;
             const int nx = r.item & 255u, ny = (r.item >> 8) & 255u, nz = (r.item >> 16) & 255u;
-            ori[el * 2] = make_ori<W, L>(nx, ny, nz, p.H);
-            if (ROT) ori[el * 2 + 1] = make_ori<W, L>(ny, nx, nz, p.H);  // utils.py:81-84
+            oo[0] = make_ori<W, L>(nx, ny, nz, p.H);
+            if (ROT) oo[1] = make_ori<W, L>(ny, nx, nz, p.H);          // utils.py:81-84
         }
     }
-    wave_sync();
+    __syncthreads();
+
+    if (MODE == kStep) {
+        // ---- phase 2b: every wave applies its bins' placements (space.py:36-46: window := max_h + z),
+        // one sub-group of 64/epw lanes per bin, rows split over the sub-group ---------------------
+        const int G = kWave >> p.epw_shift;
+        const int el = lane >> (6 - p.epw_shift), sl = lane & (G - 1);
+        if (el < nenv) {
+            const BinRec r = rec[el];
+            if (r.flags & 1u) {
+                const int lx = r.place & 255u, ly = (r.place >> 8) & 255u, x = (r.place >> 16) & 255u, y = r.place >> 24;
+                uint8_t *hb = hm + el * A + lx * L + ly;
+                const uint8_t top = (uint8_t)(r.flags >> 8);
+                for (int a = sl; a < x; a += G)
+                    for (int b = 0; b < y; ++b) hb[a * L + b] = top;
+            }
+        }
+        wave_sync();
+    }
 
     const bool late_obs = (MODE == kStep) && (p.obs_order != 0) && ((wid & 1) != 0);
     auto write_obs = [&]() {
@@ -738,12 +815,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
         // ---- phase 3b: int32 heightmap + float32 observation out (bin3D.py:49-66) -----------------
         // Odd waves emit it AFTER the mask phases instead, so that on every SIMD store-heavy and
         // VALU-heavy phases of co-resident waves interleave instead of all waves streaming at once.
-        if (!late_obs || p.mask == nullptr) write_obs();
+        if (!(p.ablate & 8) && (!late_obs || p.mask == nullptr)) write_obs();
         if (p.mask == nullptr) return;
     }
 
     // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
-    {
+    if (!(p.ablate & 1)) {
         Ent<K> zero;
 #pragma unroll
         for (int k = 0; k < K; ++k) zero.w[k] = 0;
@@ -794,7 +871,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     // (utils.py:54-55 loop ranges) are enumerated -- lane t <-> (i, j) = (t / nj, t % nj).
     for (int g = lane; g < nenv * (M / 4); g += kWave) ((uint32_t *)mk)[g] = 0u;
     wave_sync();
-    for (int el = 0; el < nenv; ++el) {
+    for (int el = 0; el < ((p.ablate & 2) ? 0 : nenv); ++el) {
         unsigned long long any = 0ull;
         const Ent<K> *Pe = P + el * PN;
         const uint8_t *he = hm + el * A;
@@ -843,7 +920,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_fast_kernel(const 
     // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
     {
         float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
-        for (int g = lane; g < nenv * (M / 4); g += kWave) {
+        for (int g = lane; g < ((p.ablate & 4) ? 0 : nenv * (M / 4)); g += kWave) {
             const uint32_t v = rec[g / (M / 4)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
             gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
         }
@@ -1063,6 +1140,8 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     p.obs_order = oo ? atoi(oo) : 0;
     const char *xr = getenv("BPP_XCD");
     p.xcd_remap = xr ? atoi(xr) : 1;
+    const char *ab = getenv("BPP_ABLATE");
+    p.ablate = ab ? atoi(ab) : 0;
     p.epw = epw;
     p.off_mk = (epw * p.A + 15) & ~15;
     p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
@@ -1077,7 +1156,8 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     const int waves = (E + epw - 1) / epw;
     l.wpb = kWavesPerBlock;
     const char *wpb = getenv("BPP_WPB");
-    if (wpb && atoi(wpb) >= 1 && atoi(wpb) <= kWavesPerBlock) l.wpb = atoi(wpb);
+    if (wpb && atoi(wpb) >= 1 && atoi(wpb) <= (l.fast >= 0 ? kMaxFastWavesPerBlock : kWavesPerBlock)) l.wpb = atoi(wpb);
+    if (l.fast >= 0 && l.wpb * epw > kWave) l.wpb = kWave / epw;  // wave 0 carries one bin per lane
     l.blocks = (waves + l.wpb - 1) / l.wpb;
     l.lds = (size_t)l.wpb * p.lds_per_wave;
     return l;

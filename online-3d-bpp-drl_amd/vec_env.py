@@ -132,7 +132,7 @@ class BppVecEnv(object):
         with torch.cuda.device(dev):
             self.pool = torch.from_numpy(self.pool_host).to(dev)
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
-            self.state = torch.zeros((self.E, 8), dtype=torch.int32, device=dev)  # bpp_env_state[E], 32 B each
+            self.state = torch.zeros((self.E, 12), dtype=torch.int32, device=dev)  # bpp_env_state[E], 48 B each
             # episode statistics accumulated inside the step kernel: [slots][return, ratio, length, count]
             self.stats_slots = torch.zeros((_lib.STATS_SLOTS, 4), dtype=torch.float64, device=dev)
         self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
@@ -284,5 +284,6 @@ class BppVecEnv(object):
     def state_numpy(self):
         """bpp_env_state[E] as a structured numpy array (tests)."""
         dt = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),
-                       ("ep_ret", "<f8"), ("ep_len", "<i4"), ("seq", "<i4")])
+                       ("ep_ret", "<f8"), ("ep_len", "<i4"), ("seq", "<i4"), ("item_cur", "<u4"), ("item_next", "<u4"),
+                       ("item_reset", "<u4"), ("pad", "<u4")])
         return self.state.cpu().numpy().view(dt).reshape(-1)

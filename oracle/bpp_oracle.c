@@ -140,6 +140,20 @@ static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item
     item[2] = p[2];
 }
 
+/* Keep the pool-entry cache of the state record coherent (see include/bpp_abi.h). */
+static uint32_t pool_entry(const bpp_batch *b, int64_t seq, int c) {
+    if (c > b->pool_len - 1) c = b->pool_len - 1;
+    const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+static void refresh_item_cache(const bpp_batch *b, bpp_env_state *s) {
+    int64_t seq_n = ((int64_t)s->seq + b->env_id_total % b->pool_size) % b->pool_size;
+    s->item_cur = pool_entry(b, s->seq, s->cursor);
+    s->item_next = pool_entry(b, s->seq, s->cursor + 1);
+    s->item_reset = pool_entry(b, seq_n, 0);
+    s->pad = 0;
+}
+
 /* PackingGame.cur_observation (envs/bpp0/bin3D.py:61-66) as float32 (shmem_vec_env.py:42-43) + mask. */
 static void write_obs_mask(const bpp_batch *b, int e, const int item[3], const bpp_step_out *out) {
     int A = b->W * b->L, M = A * (1 + b->rotation);
@@ -181,6 +195,7 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
         reset_bin(b, e, s);
         int item[3];
         next_box(b, e, s, item);
+        refresh_item_cache(b, s);
         write_obs_mask(b, e, item, out);
     }
     return 0;
@@ -264,6 +279,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
             reset_bin(b, e, s);
         }
         next_box(b, e, s, item);
+        refresh_item_cache(b, s);
         write_obs_mask(b, e, item, out);
     }
     return 0;

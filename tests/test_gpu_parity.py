@@ -119,7 +119,7 @@ def test_gpu_vs_oracle_random_rollout(bpp, oracle, kernel_path, size, rot, E, se
                 np.testing.assert_array_equal(env.location_masks.cpu().numpy(), rmask)
         np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
         st = env.state_numpy()
-        for f in ("cursor", "episode", "n_boxes", "vol_sum", "ep_ret", "ep_len", "seq"):
+        for f in ("cursor", "episode", "n_boxes", "vol_sum", "ep_ret", "ep_len", "seq", "item_cur", "item_next", "item_reset"):
             np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
 
 
