@@ -523,6 +523,107 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
     }
 }
 
+// Prefix image of ONE bin by a whole wave (used when a wave owns a single bin, e.g. the 20x20 bin
+// whose image is 7 KB): every row is split into SEG = 64/W segments so that W*SEG (60 of 64 for W = 20)
+// lanes scan concurrently; each lane scans its <= CS cells, the segment totals are exchanged with
+// __shfl_up and added as offsets.  Same for the column pass.  (With lane-per-row scans only W of 64 lanes
+// worked and this phase was 27 % of the 20^3 step.)
+template <int K>
+__device__ __forceinline__ Ent<K> shfl_up_ent(const Ent<K> &v, int d) {
+    Ent<K> r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.w[k] = (uint64_t)__shfl_up((unsigned long long)v.w[k], d, kWave);
+    return r;
+}
+
+template <int W, int L, int K>
+__device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *P, uint32_t hclamp, int lane) {
+    constexpr int PW = L + 1;
+    constexpr int SR = (kWave / W) < 1 ? 1 : (kWave / W), CSR = (L + SR - 1) / SR;  // row pass: segments along j
+    constexpr int SC = (kWave / L) < 1 ? 1 : (kWave / L), CSC = (W + SC - 1) / SC;  // column pass: segments along i
+    Ent<K> zero;
+#pragma unroll
+    for (int k = 0; k < K; ++k) zero.w[k] = 0;
+    for (int t = lane; t < PW + W; t += kWave) P[t < PW ? t : (t - PW + 1) * PW] = zero;  // row 0, column 0
+    {
+        const int i = lane / SR, sg = lane - i * SR;
+        const bool act = i < W;
+        const int j0 = sg * CSR;
+        const uint8_t *row = hm + (act ? i : 0) * L;
+        Ent<K> s[CSR];
+        Ent<K> run = zero;
+#pragma unroll
+        for (int c = 0; c < CSR; ++c) {
+            const int j = j0 + c;
+            if (j < L) {
+                const Ent<K> cd = code_of<K>(min((uint32_t)row[j], hclamp));
+#pragma unroll
+                for (int k = 0; k < K; ++k) run.w[k] += cd.w[k];
+            }
+            s[c] = run;
+        }
+        Ent<K> off = zero;
+#pragma unroll
+        for (int d = 1; d < SR; ++d) {
+            const Ent<K> t = shfl_up_ent<K>(run, d);
+            if (sg >= d) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) off.w[k] += t.w[k];
+            }
+        }
+        if (act) {
+            Ent<K> *pr = P + (i + 1) * PW + 1;
+#pragma unroll
+            for (int c = 0; c < CSR; ++c)
+                if (j0 + c < L) {
+                    Ent<K> o;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o.w[k] = s[c].w[k] + off.w[k];
+                    pr[j0 + c] = o;
+                }
+        }
+    }
+    wave_sync();
+    {
+        const int j = lane / SC, sg = lane - j * SC;
+        const bool act = j < L;
+        const int i0 = sg * CSC;
+        Ent<K> *pc = P + PW + ((act ? j : 0) + 1);
+        Ent<K> s[CSC];
+        Ent<K> run = zero;
+#pragma unroll
+        for (int c = 0; c < CSC; ++c) {
+            const int i = i0 + c;
+            if (i < W) {
+                const Ent<K> v = pc[i * PW];
+#pragma unroll
+                for (int k = 0; k < K; ++k) run.w[k] += v.w[k];
+            }
+            s[c] = run;
+        }
+        Ent<K> off = zero;
+#pragma unroll
+        for (int d = 1; d < SC; ++d) {
+            const Ent<K> t = shfl_up_ent<K>(run, d);
+            if (sg >= d) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) off.w[k] += t.w[k];
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < CSC; ++c)
+                if (i0 + c < W) {
+                    Ent<K> o;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o.w[k] = s[c].w[k] + off.w[k];
+                    pc[(i0 + c) * PW] = o;
+                }
+        }
+    }
+    wave_sync();
+}
+
 // Per-bin, per-orientation constants of the item shown in the next observation, computed once by the
 // bin's lane and read (one ds_read_b128) by every candidate lane.  The float64 ratio tests of
 // acktr/utils.py:28-33 become integer thresholds on max_area:
@@ -607,6 +708,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // scalar chain (state, action, items, placement rule, reward, Monitor, next item) and leaves a
     // record per bin in the owning wave's LDS area; the other waves wait at the barrier.  (Executing
     // this chain in every wave for only `epw` bins cost 45 % of the kernel.)
+    bool fin = false;
+    double fin_ret = 0.0, fin_ratio = 0.0;
+    int fin_len = 0;
     if (wid == 0 && !(p.ablate & 32)) {
         const bool active = lane < dec_nb;
         const int e = dec_e;
@@ -618,9 +722,6 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         r.place = 0;
         r.flags = 0;
         r.any = 0;
-        bool fin = false;
-        double fin_ret = 0.0, fin_ratio = 0.0;
-        int fin_len = 0;
         if (MODE == kStep) {
             bpp_env_state st = st0;                                    // loaded before the tile was staged
             const int64_t act = act0;
@@ -756,8 +857,6 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const int32_t *it = p.items_in + (size_t)e * 3;
             r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
         }
-        if (MODE == kStep && p.stats)
-            wave_episode_stats(p.stats, blockIdx.x, fin, fin_ret, fin_ratio, fin_len);
         if (active) {
             ((BinRec *)(ob + p.off_rec))[oel] = r;
             OriRec *oo = (OriRec *)(ob + p.off_ori) + oel * 2;
@@ -767,6 +866,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         }
     }
     __syncthreads();
+    // episode statistics (main.py:159-162): off the other waves' critical path, after the barrier
+    if (MODE == kStep && wid == 0 && p.stats && !(p.ablate & 128))
+        wave_episode_stats(p.stats, blockIdx.x, fin, fin_ret, fin_ratio, fin_len);
 
     if (MODE == kStep) {
         // ---- phase 2b: every wave applies its bins' placements (space.py:36-46: window := max_h + z),
@@ -820,7 +922,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
 
     // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
-    if (!(p.ablate & 1)) {
+    if (!(p.ablate & 1) && p.epw == 1 && W * 2 <= kWave) {
+        if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
+    } else if (!(p.ablate & 1)) {
         Ent<K> zero;
 #pragma unroll
         for (int k = 0; k < K; ++k) zero.w[k] = 0;
