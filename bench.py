@@ -150,6 +150,10 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     if rank == 0:
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            metric = "env steps/sec (whole node), 10^3 bin, 65536 envs; bit-exact mask vs ref"
         b_alg = algorithmic_bytes_per_env_step(A, M)
         achieved = b_alg * E / (kern_avg_ms * 1e-3) / 1e9
         traffic = None
@@ -160,7 +164,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env steps/sec (whole node), 10^3 bin, 65536 envs; bit-exact mask vs ref",
+            "metric": metric,
             "value": world * E * args.steps / dt,
             "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,9 +178,10 @@ def main():
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only" % world,
                        "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
                        "mean_episode_length": round(summary["mean_length"], 2)},
-            "roofline": {"bound": "hbm", "kernel": "bpp_kernel<VEC,kStep> (bpp_step)",
+            "roofline": {"bound": "hbm", "kernel": "bpp_step (bpp_fast_kernel<W,L,K,ROT,kStep>)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+                         "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
                          "launch_us_min": kern_ms[0] * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

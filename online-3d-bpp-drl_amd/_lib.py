@@ -63,8 +63,12 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB):
-            raise RuntimeError("libbpp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                               "(expected at %s)" % LIB)
+            # not a fallback: the product itself gets compiled (hipcc cross-compiles without a GPU)
+            try:
+                build()
+            except Exception as exc:  # noqa: BLE001
+                raise RuntimeError("libbpp_hip.so is missing and could not be built with hipcc (%s); run "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`" % (exc,))
         L = ctypes.CDLL(LIB)
         L.bpp_abi_version.restype = ctypes.c_int
         L.bpp_last_error.restype = ctypes.c_char_p
