@@ -1,17 +1,20 @@
 // bpp_kernels.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the vectorised 3D bin-packing
 // environment step (include/bpp_abi.h).  Hand-written for wave64; integer/indexing work, no MFMA.
 //
-// Work decomposition ("wave-autonomous bins"):
-//   * one 64-lane wavefront owns EPW consecutive bins (EPW = 16 for the 10x10 bin) for the whole
-//     step; waves never talk to each other, so there is no block-level barrier anywhere -- a
-//     256-thread workgroup is just 4 independent waves sharing an LDS allocation;
-//   * the wave's bins are contiguous in every tensor ([E][A] heightmap, [E][4A] observation,
-//     [E][M] mask), so each tensor chunk is streamed with full-width 16-byte-per-lane accesses
-//     (1 KiB per wave instruction), whatever the bin geometry;
-//   * the heightmap chunk is staged ONCE into LDS as bytes (heights <= H <= 255): EPW*A bytes per
-//     wave; placement check, heightmap update, observation and mask are all produced from that tile;
-//   * per-bin scalar work (action decode, placement rule, reward, Monitor accumulators, auto-reset,
-//     item fetch) runs lane-per-bin on the first EPW lanes; per-cell work runs lane-per-cell.
+// Two implementations of the same step share this file:
+//   * bpp_fast_kernel<W,L,K,ROT,MODE>  compile-time geometry (10x10, 20x20), the production path;
+//   * bpp_kernel<VEC,MODE>             any W*L <= 1024 (also W*L % 4 != 0), the fallback.
+// Work decomposition of the fast path:
+//   * a workgroup of 4 waves owns 4*EPW consecutive bins (EPW = 4 for the 10x10 bin, 1 for 20x20); the
+//     bins of a wave are contiguous in every tensor ([E][A] byte heightmap, [E][4A] observation, [E][M]
+//     mask), so each chunk is streamed with full-width accesses whatever the geometry;
+//   * ONE wave per workgroup carries the per-bin scalar chain lane-per-bin (state, action decode,
+//     placement rule, reward, Monitor sums, auto-reset, next item; all items come from the state record,
+//     no dependent pool lookup) and leaves a small record per bin in LDS; two workgroup barriers are the
+//     only synchronisation, workgroups never talk to each other;
+//   * every wave then works on its own bins only: placement fill, observation/heightmap store, a
+//     packed-histogram prefix image of the tile in LDS, bin-uniform candidate evaluation (item constants
+//     in scalar registers, only in-range candidates enumerated), mask store.
 //
 // Reference semantics are cited next to the code that restates them;
 // paths are relative to the reference root.
@@ -24,6 +27,14 @@
 #include "../../include/bpp_abi.h"
 
 #pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
+
+// Profiling aid, compiled in only with -DBPP_ENABLE_ABLATION (tools/build_ablation.sh): BPP_ABLATE=<bit mask>
+// then skips individual phases so their cost can be read off rocprofv3 (results are wrong when used).
+#ifdef BPP_ENABLE_ABLATION
+#define BPP_ABL(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define BPP_ABL(p, bit) false
+#endif
 
 namespace {
 
@@ -49,7 +60,6 @@ struct Params {
     int32_t lds_per_wave;  // bytes
     int32_t off_mk, off_rec, off_ori, off_P;
     int32_t epw_shift;     // epw == 1 << epw_shift on the fast path
-    int32_t obs_order;     // 1: odd waves write the observation after the mask phases
     int32_t xcd_remap;     // 1: XCD-aware block -> bins mapping
     int32_t ablate;        // profiling aid (BPP_ABLATE bit mask): skip a phase to read its cost; results are then wrong
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
@@ -669,13 +679,13 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     Ent<K> *P = (Ent<K> *)(wb + p.off_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
 
-    if (p.ablate & 16) return;
+    if (BPP_ABL(p, 16)) return;
     // The deciding wave (wave 0) issues its per-bin loads first, so their latency overlaps the staging.
     const int dec_nb = max(0, min(wpb * p.epw, p.E - blk_e0));
     const int dec_e = blk_e0 + (lane < dec_nb ? lane : 0);
     bpp_env_state st0;
     int64_t act0 = 0;
-    if (MODE == kStep && wid == 0 && !(p.ablate & 32)) {
+    if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
         st0 = p.state[dec_e];
         act0 = p.actions[dec_e];
     }
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // ---- phase 1: stage heightmaps as bytes ------------------------------------------------------
     if (MODE == kStep) {
         const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)e0 * A);
-        for (int q = lane; q < ((p.ablate & 64) ? 0 : nenv * A4); q += kWave) hm32[q] = gh[q];
+        for (int q = lane; q < (BPP_ABL(p, 64) ? 0 : nenv * A4); q += kWave) hm32[q] = gh[q];
     } else if (MODE == kMaskHmap) {
         const int4 *gh = (const int4 *)(p.hmap_in + (size_t)e0 * A);
         for (int q = lane; q < nenv * A4; q += kWave) {
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     bool fin = false;
     double fin_ret = 0.0, fin_ratio = 0.0;
     int fin_len = 0;
-    if (wid == 0 && !(p.ablate & 32)) {
+    if (wid == 0 && !BPP_ABL(p, 32)) {
         const bool active = lane < dec_nb;
         const int e = dec_e;
         const int ow = lane >> p.epw_shift, oel = lane & (p.epw - 1);  // owning wave, bin within it
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
     __syncthreads();
     // episode statistics (main.py:159-162): off the other waves' critical path, after the barrier
-    if (MODE == kStep && wid == 0 && p.stats && !(p.ablate & 128))
+    if (MODE == kStep && wid == 0 && p.stats && !BPP_ABL(p, 128))
         wave_episode_stats(p.stats, blockIdx.x, fin, fin_ret, fin_ratio, fin_len);
 
     if (MODE == kStep) {
@@ -888,7 +898,6 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         wave_sync();
     }
 
-    const bool late_obs = (MODE == kStep) && (p.obs_order != 0) && ((wid & 1) != 0);
     auto write_obs = [&]() {
         uint32_t *gh = (uint32_t *)(p.hmap + (size_t)e0 * A);
         float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
@@ -914,17 +923,15 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 if (rec[q / A4].flags & 2u) hm32[q] = 0u;
             wave_sync();
         }
-        // ---- phase 3b: int32 heightmap + float32 observation out (bin3D.py:49-66) -----------------
-        // Odd waves emit it AFTER the mask phases instead, so that on every SIMD store-heavy and
-        // VALU-heavy phases of co-resident waves interleave instead of all waves streaming at once.
-        if (!(p.ablate & 8) && (!late_obs || p.mask == nullptr)) write_obs();
+        // ---- phase 3b: byte heightmap (state) + float32 observation out (bin3D.py:49-66) ----------
+        if (!BPP_ABL(p, 8)) write_obs();
         if (p.mask == nullptr) return;
     }
 
     // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
-    if (!(p.ablate & 1) && p.epw == 1 && W * 2 <= kWave) {
+    if (!BPP_ABL(p, 1) && p.epw == 1 && W * 2 <= kWave) {
         if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
-    } else if (!(p.ablate & 1)) {
+    } else if (!BPP_ABL(p, 1)) {
         Ent<K> zero;
 #pragma unroll
         for (int k = 0; k < K; ++k) zero.w[k] = 0;
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // (utils.py:54-55 loop ranges) are enumerated -- lane t <-> (i, j) = (t / nj, t % nj).
     for (int g = lane; g < nenv * (M / 4); g += kWave) ((uint32_t *)mk)[g] = 0u;
     wave_sync();
-    for (int el = 0; el < ((p.ablate & 2) ? 0 : nenv); ++el) {
+    for (int el = 0; el < (BPP_ABL(p, 2) ? 0 : nenv); ++el) {
         unsigned long long any = 0ull;
         const Ent<K> *Pe = P + el * PN;
         const uint8_t *he = hm + el * A;
@@ -1024,12 +1031,11 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
     {
         float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
-        for (int g = lane; g < ((p.ablate & 4) ? 0 : nenv * (M / 4)); g += kWave) {
+        for (int g = lane; g < (BPP_ABL(p, 4) ? 0 : nenv * (M / 4)); g += kWave) {
             const uint32_t v = rec[g / (M / 4)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
             gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
         }
     }
-    if (late_obs) write_obs();
 }
 
 // Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
@@ -1240,8 +1246,6 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
         epw = 1 << sh;
         p.epw_shift = sh;
     }
-    const char *oo = getenv("BPP_OBS_ORDER");
-    p.obs_order = oo ? atoi(oo) : 0;
     const char *xr = getenv("BPP_XCD");
     p.xcd_remap = xr ? atoi(xr) : 1;
     const char *ab = getenv("BPP_ABLATE");
