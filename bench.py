@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/s of the fused HIP environment step (BASELINE.json config[1]).
 
-One "step" = one lock-step of all bins on this rank: device-side uniform-random-feasible action
-sampling (bpp_sample_feasible) + the fused step kernel (bpp_step: action decode, placement rule,
-heightmap update, reward, Monitor accumulators + episode statistics, auto-reset, next observation,
-feasibility mask).  Inputs (pool, state, previous mask) are resident in HBM.
+One "step" = one lock-step of all bins on this rank = ONE launch of the fused step kernel (bpp_step:
+action decode, placement rule, heightmap update, reward, Monitor accumulators + episode statistics,
+auto-reset, next observation, feasibility mask, and -- the benchmark's action source -- a uniform-random
+draw among the feasible positions of the new mask for the next lock-step).  Inputs (pool, state,
+actions) are resident in HBM.
 
     python bench.py --gpus 1 --steps 200 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -104,8 +105,8 @@ def main():
     env.reset()
 
     def lockstep(t):
-        env.sample_feasible(seed=1, step=t, out=actions)
-        return env.step_tensors(actions)      # episode statistics accumulate inside the step kernel
+        # actions for lock-step t were drawn inside lock-step t-1 (or by sample_feasible before the loop)
+        return env.step_tensors(actions, sample=(1, t + 1, actions))
 
     def fence():
         torch.cuda.synchronize(device)
@@ -127,6 +128,7 @@ def main():
     # same K lock-steps driven step by step from Python (what a Python RL loop pays per step)
     fence()
     t1 = time.perf_counter()
+    env.sample_feasible(seed=1, step=args.warmup + args.steps, out=actions)
     for t in range(args.steps):
         lockstep(args.warmup + args.steps + t)
     fence()
@@ -141,9 +143,8 @@ def main():
     n_ev = min(args.steps, 200)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for t, (e0, e1) in enumerate(evs):
-        env.sample_feasible(seed=1, step=args.warmup + 2 * args.steps + t, out=actions)
         e0.record()
-        env.step_tensors(actions)
+        lockstep(args.warmup + 2 * args.steps + t)
         e1.record()
     torch.cuda.synchronize(device)
     kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)

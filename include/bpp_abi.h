@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 3
+#define BPP_ABI_VERSION 4
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -100,6 +100,12 @@ typedef struct bpp_step_out {
     double  *ratio;    /* [E] info['ratio'] (before any auto-reset); bin3D.py:111,125              */
     double  *ep_ret;   /* [E] where done: info['episode']['r'] before round(.,6); else running sum */
     int32_t *ep_len;   /* [E] where done: info['episode']['l']; else running length                */
+    int64_t *next_action; /* NULL, or [E]: bpp_step additionally draws, from the mask it just produced, the
+                          action bpp_sample_feasible(mask, ., sample_seed, sample_step) would return --
+                          the uniform-feasible policy fused into the step (no reference counterpart;
+                          benchmark/soak driver).  May alias the `actions` argument.               */
+    uint64_t sample_seed;
+    uint64_t sample_step;
 } bpp_step_out;
 
 int bpp_abi_version(void);

@@ -13,7 +13,7 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 LIB = os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
@@ -33,7 +33,9 @@ class Batch(ctypes.Structure):
 
 class StepOut(ctypes.Structure):
     """struct bpp_step_out"""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len",
+                                               "next_action")] + [("sample_seed", ctypes.c_uint64),
+                                                                  ("sample_step", ctypes.c_uint64)]
 
 
 def hipcc():

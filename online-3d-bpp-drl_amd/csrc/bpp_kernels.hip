@@ -85,6 +85,10 @@ struct Params {
     double *ratio;
     double *ep_ret;
     int32_t *ep_len;
+    // fused uniform-feasible sampling of the next action (bpp_step_out.next_action)
+    int64_t *next_action;
+    uint64_t sample_seed, sample_step;
+    int64_t env_id_base;
 };
 
 // Per-bin record in LDS written by the bin's lane, read by the cell lanes.
@@ -149,6 +153,14 @@ __device__ __forceinline__ bool feasible(const Win &w, int area, int z, int H, i
               ((20 * w.ma > 19 * area) || (w.c == 3 && 20 * w.ma > 17 * area) || (w.c == 4 && 2 * w.ma > area));
     if (rule == BPP_RULE_SPACE) ok = ok && (w.sc >= 3);
     return ok;
+}
+
+// Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
 }
 
 // Episode statistics of bins that finished this step (main.py:159-162), summed over the wave and added
@@ -1028,6 +1040,52 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
     wave_sync();
 
+    // ---- phase 4c (optional): draw the next action uniformly among the feasible entries ------------
+    // Same result as bpp_sample_feasible on the mask this step writes: one sub-group of 64/epw lanes per
+    // bin counts the set bytes of its slice of the LDS mask, an inclusive scan inside the sub-group locates
+    // the pick-th one (pick = (hash >> 32) * count >> 32).
+    if (MODE == kStep && p.next_action != nullptr) {
+        constexpr int NQ = M / 4;
+        const int G = kWave >> p.epw_shift;
+        const int el = lane >> (6 - p.epw_shift), sl = lane & (G - 1);
+        const bool act = el < nenv;
+        const int per = (NQ + G - 1) / G;
+        const uint32_t *mq = (const uint32_t *)mk + (act ? el : 0) * NQ;
+        const bool anyf = act && rec[act ? el : 0].any != 0u;
+        int cnt = 0;
+        for (int k = 0; k < per; ++k) {
+            const int q = sl * per + k;
+            const uint32_t v = (act && q < NQ) ? (anyf ? mq[q] : 0x01010101u) : 0u;
+            cnt += (int)((v * 0x01010101u) >> 24);  // bytes are 0/1: their sum
+        }
+        int incl = cnt;
+        for (int d = 1; d < G; d <<= 1) {
+            const int o = __shfl_up(incl, d, kWave);
+            if (sl >= d) incl += o;
+        }
+        const int total = __shfl(incl, lane | (G - 1), kWave);
+        if (act && total > 0) {
+            const int e = e0 + el;
+            int rem = (int)(((mix64(p.sample_seed, (uint64_t)(p.env_id_base + e), p.sample_step) >> 32) * (uint64_t)total) >> 32);
+            const int excl = incl - cnt;
+            if (rem >= excl && rem < incl) {
+                rem -= excl;
+                int found = 0;
+                for (int k = 0; k < per; ++k) {
+                    const int q = sl * per + k;
+                    const uint32_t v = q < NQ ? (anyf ? mq[q] : 0x01010101u) : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if ((v >> (8 * t)) & 1u) {
+                            if (rem == 0) found = q * 4 + t;
+                            --rem;
+                        }
+                }
+                p.next_action[e] = found;
+            }
+        }
+    }
+
     // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
     {
         float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
@@ -1036,14 +1094,6 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
         }
     }
-}
-
-// Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
 }
 
 // Sub-groups of 16 lanes per bin (4 bins per wave): each lane owns `per` consecutive float4 quads of
@@ -1324,6 +1374,10 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.ratio = out->ratio;
     p.ep_ret = out->ep_ret;
     p.ep_len = out->ep_len;
+    p.next_action = out->next_action;
+    p.sample_seed = out->sample_seed;
+    p.sample_step = out->sample_step;
+    p.env_id_base = b->env_id_base;
     return 0;
 }
 
@@ -1361,8 +1415,14 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
     Launch l = configure(b->num_envs, b->W, b->L, b->H, b->rotation, b->mask_rule);
     rc = fill_batch(l, b, out, true);
     if (rc) return rc;
+    if (out->next_action && !out->mask) return fail(BPP_E_BADARG, "bpp_step: next_action needs mask");
     l.p.actions = actions;
-    return launch<kStep>(l, (hipStream_t)stream);
+    if (l.fast < 0) l.p.next_action = nullptr;  // the generic kernel has no fused sampler ...
+    rc = launch<kStep>(l, (hipStream_t)stream);
+    if (rc == 0 && l.fast < 0 && out->next_action)  // ... a separate launch draws from the mask it wrote
+        rc = bpp_sample_feasible(out->mask, out->next_action, b->num_envs, b->W * b->L * (1 + b->rotation),
+                                 b->env_id_base, out->sample_seed, out->sample_step, stream);
+    return rc;
 }
 
 int bpp_mask_from_obs(const float *obs, float *mask, int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation,
@@ -1421,14 +1481,19 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
                         int32_t nsteps, void *stream) {
     if (!b || !out || !out->mask || !actions) return fail(BPP_E_BADARG, "bpp_rollout_uniform: NULL pointer");
     if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform: negative nsteps");
+    if (nsteps == 0) return 0;
     const int M = b->W * b->L * (1 + b->rotation);
-    for (int t = 0; t < nsteps; ++t) {
-        int rc = bpp_sample_feasible(out->mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t, stream);
-        if (rc) return rc;
-        rc = bpp_step(b, actions, out, stream);
-        if (rc) return rc;
+    // the first action comes from the mask left by the previous reset/step; every step then draws the
+    // next one itself (bpp_step_out.next_action, in place), except the last
+    int rc = bpp_sample_feasible(out->mask, actions, b->num_envs, M, b->env_id_base, seed, step0, stream);
+    for (int t = 0; rc == 0 && t < nsteps; ++t) {
+        bpp_step_out o = *out;
+        o.next_action = t + 1 < nsteps ? actions : nullptr;
+        o.sample_seed = seed;
+        o.sample_step = step0 + (uint64_t)t + 1;
+        rc = bpp_step(b, actions, &o, stream);
     }
-    return 0;
+    return rc;
 }
 
 int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len, int32_t E,

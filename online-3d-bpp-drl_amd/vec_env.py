@@ -191,8 +191,11 @@ class BppVecEnv(object):
         self.location_masks = bufs["mask"]
         return bufs["obs"]
 
-    def step_tensors(self, actions):
-        """Enqueue one lock-step; returns device tensors, never synchronises.  actions: int64 [E] or [E,1]."""
+    def step_tensors(self, actions, sample=None):
+        """Enqueue one lock-step; returns device tensors, never synchronises.  actions: int64 [E] or [E,1].
+        sample=(seed, step, out): additionally draw, inside the step kernel, the uniform-feasible action
+        for the NEW observation into int64 tensor `out` [E] (== sample_feasible(seed, step) on the new mask;
+        `out` may be the action tensor itself)."""
         if self._first_reset:
             raise RuntimeError("call reset() before step()")
         a = actions
@@ -208,7 +211,14 @@ class BppVecEnv(object):
             self._bufs, self._out = self._alloc()
             self._res = StepTensors(**self._bufs)
             self.location_masks = self._bufs["mask"]
-        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(self._out), self._stream())
+        out = self._out
+        if sample is not None:
+            seed, step, nxt = sample
+            if nxt.device != self.device or nxt.dtype != torch.int64 or nxt.numel() != self.E or not nxt.is_contiguous():
+                raise ValueError("sample out tensor must be a contiguous int64 [E] tensor on the env's device")
+            out = _lib.StepOut.from_buffer_copy(self._out)
+            out.next_action, out.sample_seed, out.sample_step = nxt.data_ptr(), int(seed), int(step)
+        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), self._stream())
         if rc:
             _lib.check(rc)
         return self._res

@@ -282,6 +282,11 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         refresh_item_cache(b, s);
         write_obs_mask(b, e, item, out);
     }
+    if (out->next_action) {
+        if (!out->mask) return fail(BPP_E_BADARG, "bpp_step: next_action needs mask");
+        return bpp_sample_feasible(out->mask, out->next_action, b->num_envs, A * (1 + b->rotation), b->env_id_base,
+                                   out->sample_seed, out->sample_step, stream);
+    }
     return 0;
 }
 
@@ -373,7 +378,9 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
     for (int t = 0; t < nsteps; ++t) {
         int rc = bpp_sample_feasible(out->mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t, stream);
         if (rc) return rc;
-        rc = bpp_step(b, actions, out, stream);
+        bpp_step_out o = *out;
+        o.next_action = NULL;
+        rc = bpp_step(b, actions, &o, stream);
         if (rc) return rc;
     }
     return 0;

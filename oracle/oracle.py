@@ -31,7 +31,9 @@ class Batch(ctypes.Structure):
 
 
 class StepOut(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len",
+                                               "next_action")] + [("sample_seed", ctypes.c_uint64),
+                                                                  ("sample_step", ctypes.c_uint64)]
 
 
 def build(force=False):

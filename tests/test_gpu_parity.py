@@ -278,3 +278,28 @@ def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
     # fresh_outputs (default of the factory): results of earlier steps are still intact
     np.testing.assert_array_equal(held[5].cpu().numpy(), g["obs"][5].astype(np.float32))
     envs.close()
+
+
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1000), ((20, 20, 20), False, 301),
+                                         ((20, 20, 10), True, 130), ((7, 13, 8), True, 97)])
+def test_gpu_fused_next_action_equals_standalone_sampler(bpp, oracle, kernel_path, size, rot, E):
+    """bpp_step_out.next_action (drawn inside the step kernel from the LDS mask) == bpp_sample_feasible
+    on the mask the step wrote == the oracle, on both kernel paths; and whole rollouts driven by it match."""
+    import torch
+    pool = bpp.sequences.cut2_pool(size, 32, seed=3, bound=(2, min(5, min(size) // 2)))
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, env_id_base=7, env_id_total=E + 7)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=7, env_id_total=E + 7)
+    env.reset(), ref.reset()
+    a = env.sample_feasible(seed=4, step=0)
+    nxt = torch.empty_like(a)
+    for t in range(25):
+        r = env.step_tensors(a, sample=(4, t + 1, nxt))
+        o = ref.step(a.cpu().numpy())
+        np.testing.assert_array_equal(r.mask.cpu().numpy(), o["mask"])
+        np.testing.assert_array_equal(nxt.cpu().numpy(), oracle.sample_feasible(o["mask"], 4, t + 1, env_id_base=7))
+        np.testing.assert_array_equal(nxt.cpu().numpy(), env.sample_feasible(seed=4, step=t + 1).cpu().numpy())
+        a, nxt = nxt, a
+    r = env.rollout_uniform(seed=9, step0=100, nsteps=12)
+    o, _ = oracle.rollout_uniform(ref, 9, 100, 12)
+    for k in ("obs", "mask", "done", "counter", "ep_ret"):
+        np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg=k)
