@@ -141,6 +141,19 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
                         uint64_t seed, uint64_t step, void *stream);
 
+/* Masked categorical action selection of the policy head, fused.  Replaces the
+ * inference half of acktr.distributions.Categorical.forward (acktr/distributions.py:71-84) as used by
+ * Policy.act (acktr/model.py:56-68) after the linear layer:
+ *     lx = softmax(logits - 14 * (1 - mask)) + 1e-5 ;  probs = lx / sum(lx)      (FixedCategorical(probs=lx))
+ *     action  = argmax(probs)                      if deterministic            (dist.mode())
+ *             = inverse-CDF draw with u in [0,1)   otherwise                   (dist.sample(); the
+ *               reference draws with torch.multinomial, whose RNG stream is not reproducible -- here
+ *               u = (hash(seed, global bin id, step) >> 40) * 2^-24, a counter-based stream)
+ *     log_prob = log(clamp(probs[action], eps, 1 - eps)), eps = 2^-23           (dist.log_probs(action))
+ * float32 arithmetic; logits, mask: [E][M] float32; action: [E] int64; log_prob: [E] float32 (may be NULL). */
+int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                   int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream);
+
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }
  * on `stream` from one host call.  out->mask must hold the mask of the current observations (as left

@@ -1146,6 +1146,139 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t 
     }
 }
 
+// Masked categorical action selection (include/bpp_abi.h: bpp_masked_act; acktr/distributions.py:71-84,
+// acktr/model.py:56-68).  16 lanes per bin, PER float4 quads of logits and mask per lane; row maximum,
+// softmax denominator, probability total and the CDF position are reduced/scanned inside the 16-lane row
+// with shuffles.  float32 throughout (expf/logf, not the fast intrinsics).
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 16));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d, 16);
+    return v;
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, const float *mask, int64_t *action,
+                                                         float *log_prob, int E, int M, int64_t env_id_base,
+                                                         uint64_t seed, uint64_t step, int deterministic) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid >> 4, sl = threadIdx.x & 15;
+    const bool active = e < E;
+    const size_t row = (size_t)(active ? e : 0) * M;
+    const float4 *xq = (const float4 *)(logits + row), *mq = (const float4 *)(mask + row);
+    const int nq = M >> 2;
+    float z[PER][4];
+    bool in[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int qi = sl * PER + k;
+        in[k] = qi < nq;
+        const float4 x = in[k] ? xq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 m = in[k] ? mq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        z[k][0] = x.x - (1.0f - m.x) * 14.0f;  // distributions.py:76-79
+        z[k][1] = x.y - (1.0f - m.y) * 14.0f;
+        z[k][2] = x.z - (1.0f - m.z) * 14.0f;
+        z[k][3] = x.w - (1.0f - m.w) * 14.0f;
+        if (in[k]) mx = fmaxf(fmaxf(mx, fmaxf(z[k][0], z[k][1])), fmaxf(z[k][2], z[k][3]));
+    }
+    mx = row16_max(mx);
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            z[k][t] = in[k] ? expf(z[k][t] - mx) : 0.0f;
+            part += z[k][t];
+        }
+    const float sum = row16_sum(part);
+    float lane_tot = 0.0f, best = -1.0f;
+    int best_i = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float pk = in[k] ? z[k][t] / sum + 1e-5f : 0.0f;  // distributions.py:79-80
+            z[k][t] = pk;
+            lane_tot += pk;
+            if (in[k] && pk > best) {
+                best = pk;
+                best_i = (sl * PER + k) * 4 + t;
+            }
+        }
+    const float tot = row16_sum(lane_tot);
+    int a;
+    float pa;
+    if (deterministic) {  // dist.mode(): first index of the maximum
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            const float ob = __shfl_xor(best, d, 16);
+            const int oi = __shfl_xor(best_i, d, 16);
+            if (ob > best || (ob == best && oi < best_i)) {
+                best = ob;
+                best_i = oi;
+            }
+        }
+        a = best_i;
+        pa = best;
+    } else {  // inverse CDF at u * total
+        float incl = lane_tot;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const float o = __shfl_up(incl, d, 16);
+            if (sl >= d) incl += o;
+        }
+        const float u = (float)(mix64(seed, (uint64_t)(env_id_base + (active ? e : 0)), step) >> 40) * (1.0f / 16777216.0f);
+        const float target = u * tot;
+        float c = incl - lane_tot;
+        int mine = -1;
+        float pm = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                c += z[k][t];
+                if (mine < 0 && in[k] && c > target) {
+                    mine = (sl * PER + k) * 4 + t;
+                    pm = z[k][t];
+                }
+            }
+        // the first lane (lowest indices) that crossed the target wins; none -> last entry (rounding)
+        int cand = mine < 0 ? 0x7fffffff : mine;
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            const int oc = __shfl_xor(cand, d, 16);
+            const float op = __shfl_xor(pm, d, 16);
+            if (oc < cand) {
+                cand = oc;
+                pm = op;
+            }
+        }
+        if (cand == 0x7fffffff) {
+            cand = M - 1;
+            const int ls = (M - 1) >> 2, ll = ls / PER, lk = ls - ll * PER;
+            float lastp = 0.0f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (k == lk) lastp = z[k][(M - 1) & 3];
+            pm = __shfl(lastp, ll, 16);
+        }
+        a = cand;
+        pa = pm;
+    }
+    if (active && sl == 0) {
+        action[e] = a;
+        if (log_prob) {
+            const float eps = 1.1920928955078125e-7f;  // torch clamp_probs: finfo(float32).eps
+            log_prob[e] = logf(fminf(fmaxf(pa / tot, eps), 1.0f - eps));
+        }
+    }
+}
+
 // Fallback for rows that are not a multiple of 4 floats or longer than 16 * 8 quads: one wave per bin.
 __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, int64_t *actions, int E, int M,
                                                              int64_t env_id_base, uint64_t seed, uint64_t step) {
@@ -1473,6 +1606,29 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
         hipLaunchKernelGGL(sample_kernel_generic, dim3((E + 3) / 4), dim3(256), 0, st, mask, actions, E, M, env_id_base,
                            seed, step);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                   int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream) {
+    if (!logits || !mask || !action) return fail(BPP_E_BADARG, "bpp_masked_act: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_act: non-positive size");
+    if (M % 4 != 0 || M > 16 * 8 * 4) return fail(BPP_E_TOOLARGE, "bpp_masked_act: M must be a multiple of 4 and <= 512");
+    if (!aligned16(logits) || !aligned16(mask)) return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int per = (M / 4 + 15) / 16;
+    const int blocks = (E + 15) / 16;
+#define BPP_ACT(P) hipLaunchKernelGGL(masked_act_kernel<P>, dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step, deterministic)
+    switch (per) {
+        case 1: BPP_ACT(1); break;
+        case 2: BPP_ACT(2); break;
+        case 3: BPP_ACT(3); break;
+        case 4: BPP_ACT(4); break;
+        case 5: case 6: BPP_ACT(6); break;
+        default: BPP_ACT(8); break;
+    }
+#undef BPP_ACT
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }

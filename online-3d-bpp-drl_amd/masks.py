@@ -67,3 +67,23 @@ def get_rotation_mask(observation, container_size):
     """Same as acktr.utils.get_rotation_mask (acktr/utils.py:64-94): int32 ndarray [2*W*L]."""
     m = batched_mask_from_obs(observation, container_size, True)
     return m[0].to(torch.int32).cpu().numpy().reshape(-1)
+
+
+def masked_act(logits, location_masks, seed=0, step=0, deterministic=False, env_id_base=0):
+    """Fused replacement of the inference half of `Categorical.forward` + `dist.sample()/mode()` +
+    `dist.log_probs(action)` in `Policy.act` (acktr/model.py:56-68, acktr/distributions.py:71-84):
+    logits [E,M] (output of the policy's linear layer) and location_masks [E,M] float32 device tensors ->
+    (action int64 [E,1], action_log_probs float32 [E,1]).  Sampling uses a counter-based stream keyed by
+    (seed, global bin id, step) instead of torch.multinomial."""
+    dev = logits.device if logits.device.type == "cuda" else _dev()
+    x = logits.to(device=dev, dtype=torch.float32).contiguous()
+    m = location_masks.to(device=dev, dtype=torch.float32).contiguous()
+    if x.shape != m.shape or x.dim() != 2:
+        raise ValueError("logits and location_masks must both be [E, M]")
+    E, M = x.shape
+    action = torch.empty((E, 1), dtype=torch.int64, device=dev)
+    logp = torch.empty((E, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().bpp_masked_act(x.data_ptr(), m.data_ptr(), action.data_ptr(), logp.data_ptr(), E, M,
+                                             int(env_id_base), int(seed), int(step), int(bool(deterministic)), _stream(dev)))
+    return action, logp

@@ -16,6 +16,7 @@
  */
 #include "../include/bpp_abi.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -382,6 +383,49 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
         o.next_action = NULL;
         rc = bpp_step(b, actions, &o, stream);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+/* acktr/distributions.py:71-84 + torch.distributions.Categorical(probs=...) in float32, sequential sums. */
+int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                   int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream) {
+    (void)stream;
+    if (!logits || !mask || !action) return fail(BPP_E_BADARG, "bpp_masked_act: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_act: non-positive size");
+    for (int e = 0; e < E; ++e) {
+        const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+        float mx = -INFINITY, sum = 0.0f, tot = 0.0f;
+        for (int k = 0; k < M; ++k) {
+            float z = x[k] - (1.0f - m[k]) * 14.0f;
+            if (z > mx) mx = z;
+        }
+        for (int k = 0; k < M; ++k) sum += expf(x[k] - (1.0f - m[k]) * 14.0f - mx);
+        for (int k = 0; k < M; ++k) tot += expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f;
+        int a = 0;
+        if (deterministic) {
+            float best = -1.0f;
+            for (int k = 0; k < M; ++k) {
+                float pk = expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f;
+                if (pk > best) { best = pk; a = k; }
+            }
+        } else {
+            float u = (float)(mix64(seed, (uint64_t)(env_id_base + e), step) >> 40) * (1.0f / 16777216.0f);
+            float target = u * tot, c = 0.0f;
+            a = M - 1;
+            for (int k = 0; k < M; ++k) {
+                c += expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f;
+                if (c > target) { a = k; break; }
+            }
+        }
+        action[e] = a;
+        if (log_prob) {
+            float q = (expf(x[a] - (1.0f - m[a]) * 14.0f - mx) / sum + 1e-5f) / tot;
+            const float eps = 1.1920928955078125e-7f;
+            if (q < eps) q = eps;
+            if (q > 1.0f - eps) q = 1.0f - eps;
+            log_prob[e] = logf(q);
+        }
     }
     return 0;
 }

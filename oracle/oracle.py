@@ -41,7 +41,7 @@ def build(force=False):
     if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
             and os.path.getmtime(LIB) >= os.path.getmtime(HDR)):
         return LIB
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", LIB, SRC])
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"])
     return LIB
 
 
@@ -63,6 +63,8 @@ def lib():
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.bpp_rollout_uniform.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
+                                     ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -160,3 +162,13 @@ def episode_stats(done, ep_ret, ratio, ep_len, acc=None):
         acc = np.zeros(4, np.float64)
     _check(lib().bpp_episode_stats(_p(done), _p(ep_ret), _p(ratio), _p(ep_len), done.shape[0], _p(acc), None))
     return acc
+
+
+def masked_act(logits, mask, seed, step, deterministic=False, env_id_base=0):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    a = np.zeros(logits.shape[0], np.int64)
+    lp = np.zeros(logits.shape[0], np.float32)
+    _check(lib().bpp_masked_act(_p(logits), _p(mask), _p(a), _p(lp), logits.shape[0], logits.shape[1], int(env_id_base),
+                                int(seed), int(step), int(bool(deterministic)), None))
+    return a, lp

@@ -1,0 +1,88 @@
+"""masked categorical action selection (acktr/distributions.py:71-84, acktr/model.py:56-68).
+This is the one floating-point kernel of the repository, so its checker is a plain PyTorch float32
+reference of the same op.  Tolerances: log-probabilities |diff| <= 5e-6 (float32 sums of up to 512 terms
+in a different order: sequential in the oracle, tree-shaped on the GPU, vectorised in torch); the deterministic action must equal torch's argmax whenever the top-2 probabilities
+differ by more than 1e-6; a sampled action must sit where the float64 CDF crosses u*total within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+
+def torch_reference(x, m):
+    lx = torch.softmax(x - (1.0 - m) * 14.0, dim=-1) + 1e-5          # distributions.py:76-80
+    return torch.distributions.Categorical(probs=lx)                  # FixedCategorical(probs=lx)
+
+
+def make_case(E, M, seed, density=0.3):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(E, M) * rng.choice([0.1, 1.0, 4.0], size=(E, 1))).astype(np.float32)
+    m = (rng.rand(E, M) < density).astype(np.float32)
+    m[0] = 0.0                                                         # nothing feasible
+    m[1] = 1.0                                                         # everything feasible
+    return x, m
+
+
+def uniform_of(seed, gid, step):
+    mask = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (gid + 1) + 0xD1B54A32D192ED03 * (step + 1)) & mask
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+    z ^= z >> 31
+    return (z >> 40) / 16777216.0
+
+
+def check(act_fn, E, M, seed):
+    x, m = make_case(E, M, seed)
+    d = torch_reference(torch.from_numpy(x), torch.from_numpy(m))
+    probs = d.probs.numpy()
+    # deterministic
+    a, lp = act_fn(x, m, 5, 9, True)
+    top2 = np.sort(probs, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-6
+    np.testing.assert_array_equal(a[clear], probs.argmax(1)[clear])
+    np.testing.assert_allclose(lp, d.log_prob(torch.from_numpy(a)).numpy(), rtol=0, atol=5e-6)
+    # sampled
+    a, lp = act_fn(x, m, 5, 9, False)
+    np.testing.assert_allclose(lp, d.log_prob(torch.from_numpy(a)).numpy(), rtol=0, atol=5e-6)
+    cdf = np.cumsum(probs.astype(np.float64), axis=1)
+    for e in range(E):
+        u = uniform_of(5, e, 9)
+        lo = cdf[e, a[e] - 1] if a[e] > 0 else 0.0
+        assert lo - 1e-5 <= u <= cdf[e, a[e]] + 1e-5, (e, a[e], u, lo, cdf[e, a[e]])
+    return x, m, probs
+
+
+@pytest.mark.parametrize("E,M", [(300, 100), (130, 200), (50, 400), (64, 8)])
+def test_oracle_masked_act_matches_torch_reference(oracle, E, M):
+    check(lambda x, m, s, t, det: oracle.masked_act(x, m, s, t, det), E, M, seed=E + M)
+
+
+def test_oracle_masked_act_sampling_frequencies(oracle):
+    """Many draws of one row follow its distribution (chi-square-ish bound on every bucket)."""
+    rng = np.random.RandomState(3)
+    M, N = 100, 40000
+    x = np.tile((rng.randn(1, M) * 1.5).astype(np.float32), (N, 1))
+    m = np.tile((rng.rand(1, M) < 0.4).astype(np.float32), (N, 1))
+    a, _ = oracle.masked_act(x, m, 11, 0, False)
+    p = torch_reference(torch.from_numpy(x[:1]), torch.from_numpy(m[:1])).probs.numpy()[0]
+    freq = np.bincount(a, minlength=M) / N
+    assert np.abs(freq - p).max() < 4 * np.sqrt(p.max() / N) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E,M", [(4099, 100), (1000, 200), (333, 400), (40, 8), (70, 512)])
+def test_gpu_masked_act_matches_torch_reference_and_oracle(oracle, E, M):
+    import bpp_amd
+
+    def gpu(x, m, s, t, det):
+        a, lp = bpp_amd.masked_act(torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda(), s, t, det)
+        assert a.dtype == torch.int64 and tuple(a.shape) == (x.shape[0], 1) and tuple(lp.shape) == (x.shape[0], 1)
+        return a.cpu().numpy()[:, 0], lp.cpu().numpy()[:, 0]
+
+    x, m, probs = check(gpu, E, M, seed=E + M)
+    # HIP vs the C restatement: same draws except where float32 summation order moves a CDF crossing
+    for det in (True, False):
+        ag, lg = gpu(x, m, 5, 9, det)
+        ao, lo = oracle.masked_act(x, m, 5, 9, det)
+        assert (ag != ao).mean() < 0.01
+        np.testing.assert_allclose(lg[ag == ao], lo[ag == ao], rtol=0, atol=5e-6)
