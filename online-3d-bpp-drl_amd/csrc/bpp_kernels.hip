@@ -1171,12 +1171,14 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
     const size_t row = (size_t)(active ? e : 0) * M;
     const float4 *xq = (const float4 *)(logits + row), *mq = (const float4 *)(mask + row);
     const int nq = M >> 2;
+    // lane sl owns quads sl, sl+16, sl+32, ...: every load instruction of the 16-lane row is one
+    // contiguous 256-byte segment
     float z[PER][4];
     bool in[PER];
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int qi = sl * PER + k;
+        const int qi = sl + 16 * k;
         in[k] = qi < nq;
         const float4 x = in[k] ? xq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 m = in[k] ? mq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1196,20 +1198,24 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
             part += z[k][t];
         }
     const float sum = row16_sum(part);
+    float qtot[PER];
     float lane_tot = 0.0f, best = -1.0f;
     int best_i = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k)
+    for (int k = 0; k < PER; ++k) {
+        qtot[k] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float pk = in[k] ? z[k][t] / sum + 1e-5f : 0.0f;  // distributions.py:79-80
             z[k][t] = pk;
-            lane_tot += pk;
+            qtot[k] += pk;
             if (in[k] && pk > best) {
                 best = pk;
-                best_i = (sl * PER + k) * 4 + t;
+                best_i = (sl + 16 * k) * 4 + t;
             }
         }
+        lane_tot += qtot[k];
+    }
     const float tot = row16_sum(lane_tot);
     int a;
     float pa;
@@ -1225,30 +1231,31 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
         }
         a = best_i;
         pa = best;
-    } else {  // inverse CDF at u * total
-        float incl = lane_tot;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const float o = __shfl_up(incl, d, 16);
-            if (sl >= d) incl += o;
-        }
+    } else {  // inverse CDF at u * total, entries taken in index order (quad-row k, then lane)
         const float u = (float)(mix64(seed, (uint64_t)(env_id_base + (active ? e : 0)), step) >> 40) * (1.0f / 16777216.0f);
         const float target = u * tot;
-        float c = incl - lane_tot;
-        int mine = -1;
-        float pm = 0.0f;
+        float base = 0.0f, pm = 0.0f;
+        int cand = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
+        for (int k = 0; k < PER; ++k) {
+            float incl = qtot[k];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const float o = __shfl_up(incl, d, 16);
+                if (sl >= d) incl += o;
+            }
+            float c = base + incl - qtot[k];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 c += z[k][t];
-                if (mine < 0 && in[k] && c > target) {
-                    mine = (sl * PER + k) * 4 + t;
+                if (cand == 0x7fffffff && in[k] && c > target) {
+                    cand = (sl + 16 * k) * 4 + t;
                     pm = z[k][t];
                 }
             }
-        // the first lane (lowest indices) that crossed the target wins; none -> last entry (rounding)
-        int cand = mine < 0 ? 0x7fffffff : mine;
+            base += __shfl(incl, 15, 16);
+        }
+        // the lowest index that crossed the target wins; none -> last entry (rounding at u ~ 1)
 #pragma unroll
         for (int d = 8; d > 0; d >>= 1) {
             const int oc = __shfl_xor(cand, d, 16);
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
         }
         if (cand == 0x7fffffff) {
             cand = M - 1;
-            const int ls = (M - 1) >> 2, ll = ls / PER, lk = ls - ll * PER;
+            const int lq = (M - 1) >> 2, ll = lq & 15, lk = lq >> 4;
             float lastp = 0.0f;
 #pragma unroll
             for (int k = 0; k < PER; ++k)
