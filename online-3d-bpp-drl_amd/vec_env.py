@@ -282,6 +282,32 @@ class BppVecEnv(object):
             self.stats_slots.zero_()
         return acc
 
+    # ------------------------------------------------------------------ lookahead support
+    def copy_bins(self, src, dst):
+        """Overwrite bins `dst` with the complete state of bins `src` (heightmap + scalar record): the
+        device-side replacement of `copy.deepcopy(env)` in the reference's lookahead searches
+        (acktr/reorder.py:181,236, MCTS/node.py:92-137).  The copies keep `src`'s sequence position, so
+        stepping a copy plays the same upcoming items."""
+        src = torch.as_tensor(src, dtype=torch.int64, device=self.device).reshape(-1)
+        dst = torch.as_tensor(dst, dtype=torch.int64, device=self.device).reshape(-1)
+        if src.numel() != dst.numel():
+            raise ValueError("src and dst must have the same length")
+        self.hmap[dst] = self.hmap[src]
+        self.state[dst] = self.state[src]
+
+    def preview(self, k):
+        """The next `k` items of every bin, int32 [E, k, 3] -- `box_creator.preview(k)`
+        (envs/bpp0/binCreator.py:15-18) for all bins at once (the terminator repeats past the end)."""
+        st = self.state
+        cursor, seq = st[:, 0].long(), st[:, 7].long()
+        T = self.pool.shape[1]
+        idx = torch.clamp(cursor.unsqueeze(1) + torch.arange(int(k), device=self.device).unsqueeze(0), max=T - 1)
+        return self.pool[seq.unsqueeze(1), idx][:, :, :3].to(torch.int32)
+
+    def heightmaps(self):
+        """`Space.plain` of every bin as int32 [E, W, L] (the state itself is kept as bytes)."""
+        return self.hmap.view(self.E, self.W, self.L).to(torch.int32)
+
     def state_dict(self):
         """Env checkpoint (the reference never checkpoints env state; a handful of tensors here)."""
         return {"hmap": self.hmap.clone(), "state": self.state.clone(), "first_reset": self._first_reset}

@@ -303,3 +303,34 @@ def test_gpu_fused_next_action_equals_standalone_sampler(bpp, oracle, kernel_pat
     o, _ = oracle.rollout_uniform(ref, 9, 100, 12)
     for k in ("obs", "mask", "done", "counter", "ep_ret"):
         np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg=k)
+
+
+def test_gpu_lookahead_support_copy_bins_and_preview(bpp, oracle):
+    """branching a bin (copy_bins) reproduces deepcopy semantics -- the copy steps exactly
+    like an oracle env that replays the same history -- and preview(k) lists the upcoming items."""
+    import torch
+    size, E = (10, 10, 10), 64
+    pool = bpp.sequences.cut2_pool(size, 16, seed=8)
+    env = bpp.BppVecEnv(E, size, enable_rotation=True, pool=pool)
+    ref = oracle.OracleEnv(pool, size, True, E)
+    env.reset(), ref.reset()
+    for t in range(6):
+        a = env.sample_feasible(seed=1, step=t)
+        env.step_tensors(a), ref.step(a.cpu().numpy())
+    pv = env.preview(3).cpu().numpy()
+    st = ref.state
+    for e in range(E):
+        for j in range(3):
+            c = min(int(st["cursor"][e]) + j, pool.shape[1] - 1)
+            assert pv[e, j].tolist() == pool[st["seq"][e], c, :3].tolist()
+    assert torch.equal(env.heightmaps().reshape(E, -1), env.hmap.int())
+    # branch: bins 32..63 become copies of bins 0..31, then both halves take the same actions
+    env.copy_bins(torch.arange(32), torch.arange(32, 64))
+    a = env.sample_feasible(seed=2, step=0)   # masks of the copies are stale; draw for the sources only
+    a[32:] = a[:32]
+    r = env.step_tensors(a)
+    o = ref.step(np.concatenate([a[:32].cpu().numpy(), np.zeros(32, np.int64)]))
+    for k in ("obs", "mask", "done", "counter", "ratio"):
+        v = getattr(r, k).cpu().numpy()
+        np.testing.assert_array_equal(v[32:], v[:32], err_msg=k)
+        np.testing.assert_array_equal(v[:32], o[k][:32], err_msg=k)
