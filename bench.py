@@ -49,30 +49,44 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_worker(job):
+    """One host core: step a private shard of bins with the oracle for a fixed number of lock-steps."""
+    pool, size, rotation, bins, base, total, nsteps = job
+    from oracle import oracle as orc
+    env = orc.OracleEnv(pool, size, rotation, bins, env_id_base=base, env_id_total=total)
+    env.reset()
+    t0 = time.perf_counter()
+    orc.rollout_uniform(env, 1, 0, nsteps)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(pool, size, rotation, seconds):
-    """The oracle (oracle/bpp_oracle.c: scalar C port of the reference step + mask) on ONE host core,
-    same workload and policy, bounded sample.  Checker/baseline only -- never the product path."""
+    """The oracle (oracle/bpp_oracle.c: scalar C port of the reference step + mask) on the host, same
+    workload and policy, bounded sample: first one core, then one process per host core (each with its own
+    shard of bins).  Checker/baseline only -- never the product path."""
+    import multiprocessing as mp
     from oracle import oracle as orc
     orc.build()
-    E = 256
-    env = orc.OracleEnv(pool, size, rotation, E, env_id_base=0, env_id_total=E)
-    _, mask = env.reset()
-
-    def run(n, t_base):
-        nonlocal mask
-        t0 = time.perf_counter()
-        for t in range(n):
-            a = orc.sample_feasible(mask, 1, t_base + t)
-            mask = env.step(a, copy=False)["mask"]
-        return time.perf_counter() - t0
-
-    probe = 40
-    dt = run(probe, 0)
-    n = max(probe, int(seconds / max(dt / probe, 1e-9)))
-    dt = run(n, probe)
-    return {"value": E * n / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask), "
-                      "%d bins x %d lock-steps, %.1f s, same CUT-2 pool and uniform-feasible policy" % (E, n, dt)}
+    bins = 256
+    probe = 200
+    dt = _cpu_worker((pool, size, rotation, bins, 0, bins, probe))
+    per_step = dt / probe
+    n1 = max(probe, int(0.3 * seconds / per_step))
+    dt1 = _cpu_worker((pool, size, rotation, bins, 0, bins, n1))
+    single = bins * n1 / dt1
+    cores = os.cpu_count() or 1
+    nall = max(probe, int(0.6 * seconds / per_step))
+    jobs = [(pool, size, rotation, bins, c * bins, cores * bins, nall) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pw:
+        pw.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0        # includes the fork/join of the worker processes
+    busy = cores * bins * nall / wall      # whole-node rate over the wall time of the parallel section
+    return {"value": busy, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "single_core_value": single,
+            "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "
+                      "%d processes x %d bins x %d lock-steps in %.1f s (all cores), and %d bins x %d lock-steps in "
+                      "%.1f s (one core); same CUT-2 pool and uniform-feasible policy" % (cores, bins, nall, wall, bins, n1, dt1)}
 
 
 def main():
@@ -86,18 +100,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
-
     size = tuple(args.size)
     A = size[0] * size[1]
     M = A * (2 if args.rotation else 1)
     E = args.envs
     pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)       # identical on every rank
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before the HIP runtime is initialised in this process: the baseline forks one worker per core
+        cpu_base = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    # BPP_BENCH_BACKEND=gloo + BPP_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a 1-GPU box
+    # (all ranks on device 0, gloo instead of RCCL); never set by the driver.
+    backend = os.environ.get("BPP_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    dev_index = 0 if os.environ.get("BPP_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
     env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=pool, device=device,
                             env_id_base=rank * E, env_id_total=world * E)
     stats = bpp_amd.EpisodeStats(device)
@@ -176,7 +201,8 @@ def main():
             "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
                                    % (size + (" + rotation" if args.rotation else "", E)),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": args.pool,
-                       "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only" % world,
+                       "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s)"
+                                   % (world, "RCCL" if backend == "nccl" else backend),
                        "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
                        "mean_episode_length": round(summary["mean_length"], 2)},
             "roofline": {"bound": "hbm", "kernel": "bpp_step (bpp_fast_kernel<W,L,K,ROT,kStep>)",
@@ -185,8 +211,8 @@ def main():
                          "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
                          "launch_us_min": kern_ms[0] * 1e3},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
