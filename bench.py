@@ -49,44 +49,62 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def _cpu_worker(job):
-    """One host core: step a private shard of bins with the oracle for a fixed number of lock-steps."""
-    pool, size, rotation, bins, base, total, nsteps = job
+    """One host core: step a private shard of bins with the oracle until the time budget is used up;
+    returns (lock-steps done, seconds)."""
+    pool, size, rotation, bins, base, total, budget = job
     from oracle import oracle as orc
     env = orc.OracleEnv(pool, size, rotation, bins, env_id_base=base, env_id_total=total)
     env.reset()
+    done, chunk = 0, 100
     t0 = time.perf_counter()
-    orc.rollout_uniform(env, 1, 0, nsteps)
-    return time.perf_counter() - t0
+    while True:
+        orc.rollout_uniform(env, 1, done, chunk)
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= budget:
+            return done, dt
 
 
 def cpu_baseline(pool, size, rotation, seconds):
     """The oracle (oracle/bpp_oracle.c: scalar C port of the reference step + mask) on the host, same
-    workload and policy, bounded sample: first one core, then one process per host core (each with its own
-    shard of bins).  Checker/baseline only -- never the product path."""
+    workload and policy, time-bounded sample: one core alone, then one process per usable core (each with
+    its own shard of bins).  Checker/baseline only -- never the product path."""
     import multiprocessing as mp
     from oracle import oracle as orc
     orc.build()
     bins = 256
-    probe = 200
-    dt = _cpu_worker((pool, size, rotation, bins, 0, bins, probe))
-    per_step = dt / probe
-    n1 = max(probe, int(0.3 * seconds / per_step))
-    dt1 = _cpu_worker((pool, size, rotation, bins, 0, bins, n1))
+    n1, dt1 = _cpu_worker((pool, size, rotation, bins, 0, bins, 0.3 * seconds))
     single = bins * n1 / dt1
-    cores = os.cpu_count() or 1
-    nall = max(probe, int(0.6 * seconds / per_step))
-    jobs = [(pool, size, rotation, bins, c * bins, cores * bins, nall) for c in range(cores)]
-    t0 = time.perf_counter()
+    cores = min(usable_cores(), 64)
+    jobs = [(pool, size, rotation, bins, c * bins, cores * bins, 0.5 * seconds) for c in range(cores)]
     with mp.get_context("fork").Pool(cores) as pw:
-        pw.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0        # includes the fork/join of the worker processes
-    busy = cores * bins * nall / wall      # whole-node rate over the wall time of the parallel section
-    return {"value": busy, "unit": "env steps/s", "cores": cores, "kind": "port",
+        res = pw.map(_cpu_worker, jobs)
+    rate = sum(bins * n / dt for n, dt in res)     # every worker measured over its own busy interval
+    return {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port",
             "single_core_value": single,
             "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "
-                      "%d processes x %d bins x %d lock-steps in %.1f s (all cores), and %d bins x %d lock-steps in "
-                      "%.1f s (one core); same CUT-2 pool and uniform-feasible policy" % (cores, bins, nall, wall, bins, n1, dt1)}
+                      "%d processes x %d bins for %.1f s each (sum of per-process rates), and %d bins x %d lock-steps "
+                      "in %.1f s on one core; same CUT-2 pool and uniform-feasible policy; os.cpu_count()=%s"
+                      % (cores, bins, 0.5 * seconds, bins, n1, dt1, os.cpu_count())}
 
 
 def main():
