@@ -137,7 +137,8 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
 
 /* Benchmark/test action source (no reference counterpart; SURVEY.md 8d "actions for timing"):
  * uniform choice among mask==1 entries with a counter-based RNG keyed by (seed, global bin id,
- * step): pick = (hash >> 32) * count >> 32, the pick-th set entry in index order.  actions: [E] int64. */
+ * step), a 32-bit multiply-xorshift hash: pick = hash * count >> 32, the pick-th set entry in index
+ * order.  actions: [E] int64. */
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
                         uint64_t seed, uint64_t step, void *stream);
 
@@ -148,7 +149,7 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
  *     action  = argmax(probs)                      if deterministic            (dist.mode())
  *             = inverse-CDF draw with u in [0,1)   otherwise                   (dist.sample(); the
  *               reference draws with torch.multinomial, whose RNG stream is not reproducible -- here
- *               u = (hash(seed, global bin id, step) >> 40) * 2^-24, a counter-based stream)
+ *               u = (hash32(seed, global bin id, step) >> 8) * 2^-24, a counter-based stream)
  *     log_prob = log(clamp(probs[action], eps, 1 - eps)), eps = 2^-23           (dist.log_probs(action))
  * float32 arithmetic; logits, mask: [E][M] float32; action: [E] int64; log_prob: [E] float32 (may be NULL). */
 int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,

@@ -155,12 +155,20 @@ __device__ __forceinline__ bool feasible(const Win &w, int area, int z, int H, i
     return ok;
 }
 
-// Benchmark/test action source: uniform choice among mask==1 entries (include/bpp_abi.h).
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// Counter-based RNG of the benchmark/test action sources (include/bpp_abi.h): 32-bit multiply-xorshift hash
+// of (seed, global bin id, step).  The seed/step part is wave-uniform and lives on the scalar unit.
+__device__ __forceinline__ uint32_t mix32_base(uint64_t seed, uint64_t step) {
+    return ((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u)) ^
+           (((uint32_t)step + (uint32_t)(step >> 32) * 0xC2B2AE3Du) * 0x27D4EB2Fu);
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t base, uint32_t gid) {
+    uint32_t h = base ^ (gid * 0x85EBCA77u);
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
 }
 
 // Episode statistics of bins that finished this step (main.py:159-162), summed over the wave and added
@@ -1042,8 +1050,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
 
     // ---- phase 4c (optional): draw the next action uniformly among the feasible entries ------------
     // Same result as bpp_sample_feasible on the mask this step writes: one sub-group of 64/epw lanes per
-    // bin counts the set bytes of its slice of the LDS mask, an inclusive scan inside the sub-group locates
-    // the pick-th one (pick = (hash >> 32) * count >> 32).
+    // bin; a lane owns `per` consecutive dwords (4 mask bytes each) of the bin's LDS mask, byte sums come
+    // from one multiply (bytes are 0/1), an inclusive scan inside the sub-group locates the lane holding
+    // the pick-th set entry (pick = hash * count >> 32) and prefix-byte compares locate it in the dword.
     if (MODE == kStep && p.next_action != nullptr) {
         constexpr int NQ = M / 4;
         const int G = kWave >> p.epw_shift;
@@ -1056,7 +1065,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         for (int k = 0; k < per; ++k) {
             const int q = sl * per + k;
             const uint32_t v = (act && q < NQ) ? (anyf ? mq[q] : 0x01010101u) : 0u;
-            cnt += (int)((v * 0x01010101u) >> 24);  // bytes are 0/1: their sum
+            cnt += (int)((v * 0x01010101u) >> 24);
         }
         int incl = cnt;
         for (int d = 1; d < G; d <<= 1) {
@@ -1064,25 +1073,24 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             if (sl >= d) incl += o;
         }
         const int total = __shfl(incl, lane | (G - 1), kWave);
-        if (act && total > 0) {
-            const int e = e0 + el;
-            int rem = (int)(((mix64(p.sample_seed, (uint64_t)(p.env_id_base + e), p.sample_step) >> 32) * (uint64_t)total) >> 32);
-            const int excl = incl - cnt;
-            if (rem >= excl && rem < incl) {
-                rem -= excl;
-                int found = 0;
-                for (int k = 0; k < per; ++k) {
-                    const int q = sl * per + k;
-                    const uint32_t v = q < NQ ? (anyf ? mq[q] : 0x01010101u) : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if ((v >> (8 * t)) & 1u) {
-                            if (rem == 0) found = q * 4 + t;
-                            --rem;
-                        }
+        const int e = e0 + el;
+        int rem = (int)__umulhi(mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e)), (uint32_t)total) -
+                  (incl - cnt);
+        if (act && total > 0 && rem >= 0 && rem < cnt) {
+            int found = 0;
+            for (int k = 0; k < per; ++k) {
+                const int q = sl * per + k;
+                const uint32_t v = q < NQ ? (anyf ? mq[q] : 0x01010101u) : 0u;
+                const uint32_t cum = v * 0x01010101u;          // byte t = number of set entries among bytes 0..t
+                const int c = (int)(cum >> 24);
+                if (rem >= 0 && rem < c) {
+                    // first byte whose running count exceeds rem
+                    const uint32_t r = (uint32_t)rem;
+                    found = q * 4 + (int)(((cum & 255u) <= r) + (((cum >> 8) & 255u) <= r) + (((cum >> 16) & 255u) <= r));
                 }
-                p.next_action[e] = found;
+                rem -= c;
             }
+            p.next_action[e] = found;
         }
     }
 
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t 
         if (sl == 0) actions[e] = 0;
         return;
     }
-    int pick = (int)(((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)total) >> 32);
+    int pick = (int)__umulhi(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)), (uint32_t)total);
     const int excl = incl - cnt;
     if (pick >= excl && pick < incl) {
         pick -= excl;
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
         a = best_i;
         pa = best;
     } else {  // inverse CDF at u * total, entries taken in index order (quad-row k, then lane)
-        const float u = (float)(mix64(seed, (uint64_t)(env_id_base + (active ? e : 0)), step) >> 40) * (1.0f / 16777216.0f);
+        const float u = (float)(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + (active ? e : 0))) >> 8) * (1.0f / 16777216.0f);
         const float target = u * tot;
         float base = 0.0f, pm = 0.0f;
         int cand = 0x7fffffff;
@@ -1308,7 +1316,7 @@ __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, 
         if (lane == 0) actions[e] = 0;
         return;
     }
-    int pick = (int)(((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)total) >> 32);
+    int pick = (int)__umulhi(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)), (uint32_t)total);
     const int excl = incl - cnt;
     if (pick >= excl && pick < incl) {
         pick -= excl;

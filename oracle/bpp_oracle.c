@@ -321,11 +321,18 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
     return 0;
 }
 
-static uint64_t mix64(uint64_t seed, uint64_t gid, uint64_t step) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xD1B54A32D192ED03ull * (step + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+/* Counter-based RNG of the benchmark/test action sources (no reference counterpart): a 32-bit
+ * multiply-xorshift hash of (seed, global bin id, step). */
+static uint32_t mix32(uint64_t seed, uint64_t gid, uint64_t step) {
+    uint32_t h = ((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u)) ^
+                 (((uint32_t)step + (uint32_t)(step >> 32) * 0xC2B2AE3Du) * 0x27D4EB2Fu);
+    h ^= (uint32_t)gid * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
 }
 
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
@@ -341,7 +348,7 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
             actions[e] = 0;
             continue;
         }
-        uint64_t pick = ((mix64(seed, (uint64_t)(env_id_base + e), step) >> 32) * (uint64_t)cnt) >> 32;
+        uint64_t pick = ((uint64_t)mix32(seed, (uint64_t)(env_id_base + e), step) * (uint64_t)cnt) >> 32;
         int64_t a = 0;
         for (int k = 0; k < M; ++k)
             if (m[k] != 0.0f) {
@@ -410,7 +417,7 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
                 if (pk > best) { best = pk; a = k; }
             }
         } else {
-            float u = (float)(mix64(seed, (uint64_t)(env_id_base + e), step) >> 40) * (1.0f / 16777216.0f);
+            float u = (float)(mix32(seed, (uint64_t)(env_id_base + e), step) >> 8) * (1.0f / 16777216.0f);
             float target = u * tot, c = 0.0f;
             a = M - 1;
             for (int k = 0; k < M; ++k) {

@@ -23,12 +23,16 @@ def make_case(E, M, seed, density=0.3):
 
 
 def uniform_of(seed, gid, step):
-    mask = (1 << 64) - 1
-    z = (seed + 0x9E3779B97F4A7C15 * (gid + 1) + 0xD1B54A32D192ED03 * (step + 1)) & mask
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
-    z ^= z >> 31
-    return (z >> 40) / 16777216.0
+    """The counter-based stream of include/bpp_abi.h: 32-bit multiply-xorshift hash, top 24 bits."""
+    m32 = 0xFFFFFFFF
+    h = ((seed & m32) ^ (((seed >> 32) * 0x9E3779B1) & m32)) ^ ((((step & m32) + (step >> 32) * 0xC2B2AE3D) * 0x27D4EB2F) & m32)
+    h ^= (gid * 0x85EBCA77) & m32
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & m32
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & m32
+    h ^= h >> 16
+    return (h >> 8) / 16777216.0
 
 
 def check(act_fn, E, M, seed):
