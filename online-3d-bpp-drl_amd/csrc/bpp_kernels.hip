@@ -1014,6 +1014,11 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                            oc = __builtin_amdgcn_readfirstlane(ov.c), od = __builtin_amdgcn_readfirstlane(ov.d);
             if (!(oa & (1u << 26))) continue;                          // item does not fit at all
             const int x = oa & 255u, y = (oa >> 8) & 255u, hz1 = (oa >> 16) & 511u;
+            if (ROT && rot == 1 && x == y) {
+                // square footprint: the turned item's mask (utils.py:81-89) equals the first half
+                for (int g = lane; g < A4; g += kWave) ((uint32_t *)me)[A4 + g] = ((const uint32_t *)me)[g];
+                continue;
+            }
             const bool big = (oa >> 25) & 1u;
             const int nj = (int)(oc >> 24) + 1, nv = ((int)((oc >> 16) & 255u) + 1) * nj;
             const int t95 = ob & 0xffffu, t85 = ob >> 16, t50 = oc & 0xffffu;
