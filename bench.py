@@ -7,7 +7,7 @@ auto-reset, next observation, feasibility mask, and -- the benchmark's action so
 draw among the feasible positions of the new mask for the next lock-step).  Inputs (pool, state,
 actions) are resident in HBM.
 
-    python bench.py --gpus 1 --steps 200 --warmup 50
+    python bench.py --gpus 1 --steps 500 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -38,8 +38,8 @@ def algorithmic_bytes_per_env_step(A, M):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=65536, help="bins per GPU (weak scaling)")
     ap.add_argument("--size", type=int, nargs=3, default=[10, 10, 10])
     ap.add_argument("--rotation", action="store_true")
