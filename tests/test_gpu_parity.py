@@ -334,3 +334,32 @@ def test_gpu_lookahead_support_copy_bins_and_preview(bpp, oracle):
         v = getattr(r, k).cpu().numpy()
         np.testing.assert_array_equal(v[32:], v[:32], err_msg=k)
         np.testing.assert_array_equal(v[:32], o[k][:32], err_msg=k)
+
+
+@pytest.mark.parametrize("size,rot,E,steps", [((10, 10, 10), False, 2048, 1500), ((10, 10, 10), True, 1024, 800),
+                                               ((20, 20, 20), False, 256, 400)])
+def test_gpu_long_soak_matches_oracle(bpp, oracle, size, rot, E, steps):
+    """Long horizon: thousands of lock-steps (hundreds of episodes per bin, pool rows wrapping around many
+    times) through the native driver with the in-kernel draw; final observation, mask, byte heightmaps,
+    complete state records (incl. the float64 Monitor sums and the item cache) and the episode statistics
+    must equal the oracle's."""
+    pool = bpp.sequences.cut2_pool(size, 7, seed=21)          # tiny pool -> heavy wrap-around
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, env_id_base=3, env_id_total=E + 11)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 11)
+    env.reset(), ref.reset()
+    done_steps = 0
+    for chunk in (steps // 3, steps - steps // 3):
+        r = env.rollout_uniform(seed=5, step0=done_steps, nsteps=chunk)
+        o, _ = oracle.rollout_uniform(ref, 5, done_steps, chunk)
+        done_steps += chunk
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg=k)
+    np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    st = env.state_numpy()
+    for f in st.dtype.names:
+        if f != "pad":
+            np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
+    got, want = env.episode_stats().cpu().numpy(), ref.stats.sum(0)
+    np.testing.assert_array_equal(got[2:], want[2:])
+    np.testing.assert_allclose(got[:2], want[:2], rtol=1e-11)
+    assert want[3] > E * steps / 60
