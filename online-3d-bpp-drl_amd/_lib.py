@@ -47,14 +47,23 @@ def hipcc():
 
 def build(force=False, verbose=False):
     """Compile csrc/bpp_kernels.hip for gfx950 into csrc/libbpp_hip.so (in-tree; no-op when fresh)."""
-    if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
-            and os.path.getmtime(LIB) >= os.path.getmtime(HDR)):
+    def fresh():
+        return (os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
+                and os.path.getmtime(LIB) >= os.path.getmtime(HDR))
+
+    if not force and fresh():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:      # several ranks may get here at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                   "-o", tmp, SRC]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
     return LIB
 
 
