@@ -1438,10 +1438,11 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
             }
     const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * kFastGeo[l.fast].K : 0;
     if (l.fast >= 0 && !(env && atoi(env) > 0)) {
-        // prefix image dominates LDS: keep a 4-wave block near 20 KiB (8 blocks = 32 waves per CU);
-        // measured best on MI355X for the 10x10 bin (EPW=4: 41 us vs 45 us at EPW=8, 49 us at EPW=2)
+        // prefix image dominates LDS: keep a 4-wave block under 24 KiB (>= 6 blocks = 24 waves per CU).
+        // Measured on MI355X: 10x10: EPW=4 39 us vs 43 us at EPW=8 and 50 us at EPW=2; 10x10 + rotation
+        // (21 KiB at EPW=4): 51 us vs 59 us at EPW=2; 20x20: EPW=1 85 us vs 116 us at EPW=2.
         epw = 16;
-        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 48 + pn_bytes)) > 20 * 1024) epw >>= 1;
+        while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 48 + pn_bytes)) > 24 * 1024) epw >>= 1;
     }
     if (l.fast >= 0) {  // sub-groups of 64/epw lanes per bin: epw must be a power of two <= 64
         int sh = 0;
