@@ -23,11 +23,26 @@ from .spaces import Box, Discrete
 class StepTensors(object):
     """Device-resident result of one lock-step (views of the env's output buffers unless the env was
     built with fresh_outputs=True)."""
-    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")
+    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs")
 
     def __init__(self, **kw):
         for k in self.__slots__:
-            setattr(self, k, kw[k])
+            setattr(self, k, kw.get(k))
+
+    def host_scalars(self):
+        """reward, done, counter, ratio, ep_ret, ep_len as numpy arrays with ONE device->host copy."""
+        E = self.done.numel()
+        if self._small is None:
+            return dict(reward=self.reward.cpu().numpy().reshape(E), done=self.done.cpu().numpy(),
+                        counter=self.counter.cpu().numpy(), ratio=self.ratio.cpu().numpy(),
+                        ep_ret=self.ep_ret.cpu().numpy(), ep_len=self.ep_len.cpu().numpy())
+        h = self._small.cpu().numpy()
+        o = self._offs
+        return dict(reward=h[o["reward"]:o["reward"] + 4 * E].view("<f4"), done=h[o["done"]:o["done"] + E],
+                    counter=h[o["counter"]:o["counter"] + 4 * E].view("<i4"),
+                    ratio=h[o["ratio"]:o["ratio"] + 8 * E].view("<f8"),
+                    ep_ret=h[o["ep_ret"]:o["ep_ret"] + 8 * E].view("<f8"),
+                    ep_len=h[o["ep_len"]:o["ep_len"] + 4 * E].view("<i4"))
 
 
 class LazyInfos(object):
@@ -46,8 +61,15 @@ class LazyInfos(object):
     def _fetch(self):
         if self._host is None:
             r = self._res
-            self._host = dict(done=r.done.cpu().numpy().astype(bool), counter=r.counter.cpu().numpy(),
-                              ratio=r.ratio.cpu().numpy(), ep_ret=r.ep_ret.cpu().numpy(), ep_len=r.ep_len.cpu().numpy())
+            if hasattr(r, "host_scalars"):
+                h = dict(r.host_scalars())
+            else:
+                h = dict(done=r.done.cpu().numpy(), counter=r.counter.cpu().numpy(), ratio=r.ratio.cpu().numpy(),
+                         ep_ret=r.ep_ret.cpu().numpy(), ep_len=r.ep_len.cpu().numpy())
+                if getattr(r, "reward", None) is not None:
+                    h["reward"] = r.reward.cpu().numpy().reshape(-1)
+            h["done"] = h["done"].astype(bool)
+            self._host = h
         return self._host
 
     def __len__(self):
@@ -152,16 +174,28 @@ class BppVecEnv(object):
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         E, dev = self.E, self.device
+        # the six small per-bin outputs live in ONE byte buffer (8-byte aligned slices) so the
+        # reference-shaped step_wait() needs a single device->host copy
+        offs, total = {}, 0
+        for name, width in (("ratio", 8), ("ep_ret", 8), ("reward", 4), ("counter", 4), ("ep_len", 4), ("done", 1)):
+            offs[name] = total
+            total += (E * width + 7) // 8 * 8
+        small = torch.empty((total,), dtype=torch.uint8, device=dev)
+
+        def view(name, dtype, width):
+            return small[offs[name]:offs[name] + E * width].view(dtype)
+
         b = dict(obs=torch.empty((E, self.obs_len), dtype=torch.float32, device=dev),
                  mask=torch.empty((E, self.M), dtype=torch.float32, device=dev) if self.compute_mask else None,
-                 reward=torch.empty((E, 1), dtype=torch.float32, device=dev),
-                 done=torch.empty((E,), dtype=torch.uint8, device=dev),
-                 counter=torch.empty((E,), dtype=torch.int32, device=dev),
-                 ratio=torch.empty((E,), dtype=torch.float64, device=dev),
-                 ep_ret=torch.empty((E,), dtype=torch.float64, device=dev),
-                 ep_len=torch.empty((E,), dtype=torch.int32, device=dev))
+                 reward=view("reward", torch.float32, 4).view(E, 1),
+                 done=view("done", torch.uint8, 1),
+                 counter=view("counter", torch.int32, 4),
+                 ratio=view("ratio", torch.float64, 8),
+                 ep_ret=view("ep_ret", torch.float64, 8),
+                 ep_len=view("ep_len", torch.int32, 4))
         out = _lib.StepOut(*[(b[k].data_ptr() if b[k] is not None else None)
                              for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
+        b["_small"], b["_offs"] = small, offs
         return b, out
 
     def _buffers(self):
@@ -248,9 +282,9 @@ class BppVecEnv(object):
         if r is None:
             raise RuntimeError("step_wait() without step_async()")
         infos = LazyInfos(self, r, time.time())
-        reward = r.reward.cpu()                     # CPU float32 [E,1], acktr/envs.py:192
-        done = infos._fetch()["done"]               # numpy bool [E]
-        return r.obs, reward, done, infos
+        h = infos._fetch()                          # one device->host copy for all per-bin scalars
+        reward = torch.from_numpy(np.array(h["reward"], dtype=np.float32)).unsqueeze(1)  # CPU [E,1], acktr/envs.py:192
+        return r.obs, reward, h["done"], infos
 
     def step(self, actions):
         self.step_async(actions)
