@@ -46,12 +46,13 @@ constexpr int kMaxDim = 255;    // W, L, H and item sizes are bytes
 
 enum Mode { kStep = 0, kResetInit = 1, kResetAdvance = 2, kMaskObs = 3, kMaskHmap = 4 };
 
-// n / d for n * d < 2^32 via one v_mul_hi_u32 (m = floor(2^32 / d) + 1).
+// n / d for n * d < 2^32 via one v_mul_hi_u32 (m = floor(2^32 / d) + 1); d == 1 has no 32-bit magic
+// number (2^32 + 1) and is passed through.
 struct FastDiv {
     uint32_t d, m;
-    __device__ __forceinline__ uint32_t div(uint32_t n) const { return __umulhi(n, m); }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1u ? n : __umulhi(n, m); }
 };
-FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, (uint32_t)((1ull << 32) / d) + 1u}; }
+FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, d <= 1u ? 0u : (uint32_t)((1ull << 32) / d) + 1u}; }
 
 struct Params {
     // geometry

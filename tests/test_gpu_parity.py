@@ -79,7 +79,8 @@ def test_gpu_dropin_mask_functions(bpp):
 GEOMS = [((10, 10, 10), False, 1024, 11), ((10, 10, 10), True, 1000, 12), ((20, 20, 20), False, 160, 13),
          ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16),
          ((20, 20, 10), True, 130, 17), ((20, 20, 22), True, 67, 18), ((10, 10, 7), True, 203, 19),
-         ((10, 10, 11), False, 50, 20)]
+         ((10, 10, 11), False, 50, 20), ((2, 2, 5), True, 40, 21), ((1, 3, 4), False, 33, 22), ((3, 1, 4), True, 20, 23),
+         ((1, 1, 3), True, 17, 24)]
 
 
 @pytest.mark.parametrize("size,rot,E,seed", GEOMS)
@@ -363,3 +364,26 @@ def test_gpu_long_soak_matches_oracle(bpp, oracle, size, rot, E, steps):
     np.testing.assert_array_equal(got[2:], want[2:])
     np.testing.assert_allclose(got[:2], want[:2], rtol=1e-11)
     assert want[3] > E * steps / 60
+
+
+def test_gpu_masks_property_random_geometries(bpp, oracle):
+    """Random small geometries / heightmaps / items (incl. items larger than the bin, heights above H):
+    both mask kernels' entry points == the oracle for both rules and both rotation settings."""
+    rng = np.random.RandomState(99)
+    for trial in range(60):
+        W, L, H = rng.randint(1, 14), rng.randint(1, 14), rng.randint(1, 15)
+        n = rng.randint(1, 40)
+        hm = rng.randint(0, H + 2, size=(n, W * L)).astype(np.int32)          # some cells above H
+        hm[rng.rand(n) < 0.4] = rng.randint(0, H + 1)                         # some flat maps
+        items = np.stack([rng.randint(1, W + 2, n), rng.randint(1, L + 2, n), rng.randint(1, H + 1, n)], 1).astype(np.int32)
+        size = (W, L, H)
+        A = W * L
+        obs = np.concatenate([hm, np.repeat(items[:, 0:1], A, 1), np.repeat(items[:, 1:2], A, 1),
+                              np.repeat(items[:, 2:3], A, 1)], 1).astype(np.float32)
+        for rot in (False, True):
+            for rule, rname in ((0, "utils"), (1, "space")):
+                want = oracle.mask_from_hmap(hm, items, size, rot, rule)
+                np.testing.assert_array_equal(bpp.batched_mask_from_hmap(hm, items, size, rot, rname).cpu().numpy(), want,
+                                              err_msg="hmap %r rot=%d rule=%d" % (size, rot, rule))
+                np.testing.assert_array_equal(bpp.batched_mask_from_obs(obs, size, rot, rname).cpu().numpy(), want,
+                                              err_msg="obs %r rot=%d rule=%d" % (size, rot, rule))
