@@ -92,7 +92,7 @@ def test_gpu_vs_oracle_random_rollout(bpp, oracle, kernel_path, size, rot, E, se
     lo, hi = 1, max(2, min(size) // 2)
     seqs = [[tuple(rng.randint(lo, hi + 1, size=3)) for _ in range(rng.randint(3, 60))] for _ in range(37)]
     seqs[3][1] = (size[0], size[1], 1)       # bin-sized footprints: windows far above 31 cells
-    seqs[5][0] = (size[0], size[1] - 1, 2)
+    seqs[5][0] = (size[0], max(1, size[1] - 1), 2)
     pool = bpp.sequences.pad_pool(seqs, size)
     for rule in ("utils", "space"):
         env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, mask_rule=rule, env_id_base=5, env_id_total=E + 9)
