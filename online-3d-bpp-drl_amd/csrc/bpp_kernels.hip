@@ -929,11 +929,17 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             go[q + el * (3 * A4)] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
                                                 (float)(v >> 24));
         }
-        for (int g = lane; g < nenv * 3 * A4; g += kWave) {
-            const int el = g / (3 * A4);
-            const int r3 = g - el * (3 * A4);
-            const float f = (float)((rec[el].item >> (8 * (r3 / A4))) & 255u);
-            go[g + (el + 1) * A4] = make_float4(f, f, f, f);
+        // planes x, y, z are constants per bin (bin3D.py:49-53): bin-uniform passes, the value comes from a
+        // scalar register and every lane keeps one fixed offset
+        for (int el = 0; el < nenv; ++el) {
+            const uint32_t item = __builtin_amdgcn_readfirstlane(rec[el].item);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const float f = (float)((item >> (8 * pl)) & 255u);
+                const float4 v = make_float4(f, f, f, f);
+                float4 *gp = go + el * A + (pl + 1) * A4;
+                for (int k = lane; k < A4; k += kWave) gp[k] = v;
+            }
         }
     };
 
