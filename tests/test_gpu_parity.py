@@ -387,3 +387,34 @@ def test_gpu_masks_property_random_geometries(bpp, oracle):
                                               err_msg="hmap %r rot=%d rule=%d" % (size, rot, rule))
                 np.testing.assert_array_equal(bpp.batched_mask_from_obs(obs, size, rot, rname).cpu().numpy(), want,
                                               err_msg="obs %r rot=%d rule=%d" % (size, rot, rule))
+
+
+def test_gpu_config0_shape_rs_16_envs_through_the_factory(bpp, oracle):
+    """BASELINE.json configs[0] shape: 10x10x10, --item-seq rs, 16 envs, driven through the reference-shaped
+    factory and step() with a loop written like main.py:148-174 (per-row mask helper, infos scan); every
+    value equals the oracle fed the factory's own pool."""
+    import types
+    import torch
+    box_set = [(i, j, k) for i in range(2, 6) for j in range(2, 6) for k in range(2, 6)]   # arguments.py:122-128
+    args = types.SimpleNamespace(container_size=(10, 10, 10), enable_rotation=False, data_type="rs", box_size_set=box_set)
+    envs = bpp.make_vec_envs("Bpp-v0", 1, 16, 1.0, None, "cuda:0", False, args=args, pool_size=64)
+    ref = oracle.OracleEnv(envs.pool_host, (10, 10, 10), False, 16)
+    obs = envs.reset()
+    robs, rmask = ref.reset()
+    rng = np.random.RandomState(0)
+    episode_rewards = []
+    for t in range(80):
+        location_masks = [bpp.get_possible_position(o, args.container_size) for o in obs]     # main.py:163-169
+        np.testing.assert_array_equal(np.array(location_masks, np.float32), rmask)
+        action = torch.tensor([[int(rng.choice(np.flatnonzero(m)))] for m in location_masks])
+        obs, reward, done, infos = envs.step(action)
+        o = ref.step(action.numpy()[:, 0])
+        for i in range(len(infos)):                                                            # main.py:159-162
+            if "episode" in infos[i].keys():
+                episode_rewards.append(infos[i]["episode"]["r"])
+                assert infos[i]["episode"]["r"] == round(float(o["ep_ret"][i]), 6)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o["obs"])
+        np.testing.assert_array_equal(reward.numpy()[:, 0], o["reward"])
+        np.testing.assert_array_equal(done, o["done"].astype(bool))
+        rmask = o["mask"]
+    assert len(episode_rewards) > 20
