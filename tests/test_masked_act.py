@@ -90,3 +90,48 @@ def test_gpu_masked_act_matches_torch_reference_and_oracle(oracle, E, M):
         ao, lo = oracle.masked_act(x, m, 5, 9, det)
         assert (ag != ao).mean() < 0.01
         np.testing.assert_allclose(lg[ag == ao], lo[ag == ao], rtol=0, atol=5e-6)
+
+
+def test_oracle_masked_act_against_the_reference_policy_head(oracle):
+    """Build container only: the REFERENCE's own Policy (acktr/model.py) built on this package's spaces,
+    fed observations/masks produced by the oracle env; its `Categorical.forward` + `mode()` + `log_probs()`
+    (acktr/distributions.py:71-84, acktr/model.py:56-68) are what bpp_masked_act must reproduce."""
+    from oracle import ref_shims
+    if not ref_shims.available():
+        pytest.skip("reference tree not present")
+    import types
+    import bpp_amd
+    ref_shims.install()
+    from acktr.model import Policy
+    from acktr.storage import RolloutStorage
+    for rot in (False, True):
+        size, E = (10, 10, 10), 64
+        args = types.SimpleNamespace(channel=4, container_size=size, pallet_size=10, enable_rotation=rot)
+        obs_space, act_space = bpp_amd.Box(0.0, 10, (400,)), bpp_amd.Discrete(100 * (1 + rot))
+        torch.manual_seed(0)
+        policy = Policy(obs_space.shape, act_space, base_kwargs={"recurrent": False, "hidden_size": 256, "args": args})
+        RolloutStorage(5, E, obs_space.shape, act_space, policy.recurrent_hidden_state_size, can_give_up=False,
+                       enable_rotation=rot, pallet_size=10)                       # accepts the spaces as well
+        env = oracle.OracleEnv(bpp_amd.sequences.cut2_pool(size, 16, seed=0), size, rot, E)
+        obs, mask = env.reset()
+        for t in range(6):
+            a = oracle.sample_feasible(mask, 3, t)
+            o = env.step(a)
+            obs, mask = o["obs"], o["mask"]
+        with torch.no_grad():
+            ot, mt = torch.from_numpy(obs), torch.from_numpy(mask)
+            value, action, logp, _ = policy.act(ot, None, None, mt, deterministic=True)
+            _, features, _, _ = policy.base(ot, None, None)
+            logits = policy.dist.linear(features).numpy() * 50.0       # the head's own logits, spread out
+            dist, _, _ = policy.dist(features, mt)                     # un-scaled: the reference's own path
+            a0, lp0 = oracle.masked_act(policy.dist.linear(features).numpy(), mask, 0, 0, True)
+            np.testing.assert_allclose(lp0, dist.log_probs(torch.from_numpy(a0).unsqueeze(1)).numpy()[:, 0], atol=5e-6)
+            top2 = np.sort(dist.probs.numpy(), 1)[:, -2:]
+            clear = (top2[:, 1] - top2[:, 0]) > 1e-6
+            np.testing.assert_array_equal(a0[clear], action.numpy()[clear, 0])
+            # spread-out logits: compare against the reference formula applied to them
+            lx = torch.softmax(torch.from_numpy(logits) - (1 - mt) * 14, -1) + 1e-5
+            d2 = torch.distributions.Categorical(probs=lx)
+            a1, lp1 = oracle.masked_act(logits, mask, 5, 1, False)
+            np.testing.assert_allclose(lp1, d2.log_prob(torch.from_numpy(a1)).numpy(), atol=5e-6)
+            assert (mask[np.arange(E), a1] == 1).mean() > 0.95          # draws land on feasible positions
