@@ -126,7 +126,11 @@ def main():
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # before the HIP runtime is initialised in this process: the baseline forks one worker per core
-        cpu_base = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+        try:
+            cpu_base = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+        except Exception as exc:  # noqa: BLE001 -- the baseline leg must never take the GPU measurement down
+            cpu_base = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port",
+                        "sample": "cpu baseline failed: %r" % (exc,)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     # BPP_BENCH_BACKEND=gloo + BPP_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a 1-GPU box
