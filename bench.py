@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--size", type=int, nargs=3, default=[10, 10, 10])
     ap.add_argument("--rotation", action="store_true")
     ap.add_argument("--pool", type=int, default=8192, help="CUT-2 sequences in the pool")
+    ap.add_argument("--pool-file", default=None,
+                    help="npz with a uint8 [P][T][4] `pool` array instead of generated sequences, e.g. "
+                         "tests/golden/cut2_dataset_10.npz = the reference's dataset/cut_2.pt (2100 sequences)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -122,7 +125,11 @@ def main():
     A = size[0] * size[1]
     M = A * (2 if args.rotation else 1)
     E = args.envs
-    pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)       # identical on every rank
+    if args.pool_file:
+        import numpy as np
+        pool = np.load(args.pool_file)["pool"]
+    else:
+        pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)   # identical on every rank
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # before the HIP runtime is initialised in this process: the baseline forks one worker per core
@@ -222,7 +229,8 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
                                    % (size + (" + rotation" if args.rotation else "", E)),
-                       "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": args.pool,
+                       "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
+                       "pool_source": args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)",
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s)"
                                    % (world, "RCCL" if backend == "nccl" else backend),
                        "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
