@@ -1414,7 +1414,7 @@ struct Launch {
 struct FastGeo {
     int W, L, K;
 };
-constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}};
+constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}, {10, 10, 2}};
 constexpr int kNumFastGeo = sizeof(kFastGeo) / sizeof(kFastGeo[0]);
 
 Launch configure(int E, int W, int L, int H, int rotation, int rule) {
@@ -1499,6 +1499,8 @@ int launch(const Launch &l, hipStream_t s) {
         launch_fast<20, 20, 1, MODE>(l, s);
     else if (l.fast == 2)
         launch_fast<20, 20, 2, MODE>(l, s);
+    else if (l.fast == 3)
+        launch_fast<10, 10, 2, MODE>(l, s);
     else if (l.vec)
         hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
     else
