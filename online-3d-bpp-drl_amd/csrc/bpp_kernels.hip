@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/bpp_abi.h"
 
 #pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
@@ -881,6 +883,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             st.pad = 0;
             if (active) p.state[e] = st;
             r.item = st.item_cur;
+            r.flags = 2u;
         } else if (MODE == kMaskObs) {
             const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
             r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
@@ -1014,6 +1017,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         const Ent<K> *Pe = P + el * PN;
         const uint8_t *he = hm + el * A;
         uint8_t *me = mk + el * M;
+        // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
+        const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
+                           (__builtin_amdgcn_readfirstlane(rec[el].flags) & 2u) != 0u;
 #pragma unroll
         for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
             const OriRec ov = ori[el * 2 + rot];
@@ -1030,31 +1036,48 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const int nj = (int)(oc >> 24) + 1, nv = ((int)((oc >> 16) & 255u) + 1) * nj;
             const int t95 = ob & 0xffffu, t85 = ob >> 16, t50 = oc & 0xffffu;
             const int o10 = (x - 1) * L, o01 = y - 1;
-            for (int t = lane; t < nv; t += kWave) {
-                const int i = (int)(((uint32_t)t * od) >> 16), j = t - i * nj;
-                const Ent<K> *Pb = Pe + i * PW + j;
-                int mh, ma;
-                if (!big) {
-                    const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
-                    Ent<K> h;
+            // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
+            auto run = [&](auto big_c, auto empty_c) {
+                constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
+                for (int t = lane; t < nv; t += kWave) {
+                    const int i = (int)(((uint32_t)t * od) >> 16), j = t - i * nj;
+                    bool f;
+                    if (EMPTY) {
+                        f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
+                    } else {
+                        const Ent<K> *Pb = Pe + i * PW + j;
+                        int mh, ma;
+                        if (!BIG) {
+                            const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                            Ent<K> h;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
-                    top_of<K>(h, mh, ma);
-                } else {
-                    window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                            for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
+                            top_of<K>(h, mh, ma);
+                        } else {
+                            window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                        }
+                        const uint8_t *hb = he + i * L + j;
+                        const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+                        const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
+                        const int thr = cnt == 4 ? t50 : (cnt == 3 ? t85 : t95);
+                        f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
+                        if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
+                            const int rm = max(max(r00, r10), max(r01, r11));
+                            f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+                        }
+                    }
+                    me[rot * A + i * L + j] = f ? 1 : 0;
+                    any |= __ballot(f);
                 }
-                const uint8_t *hb = he + i * L + j;
-                const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
-                const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
-                const int thr = cnt == 4 ? t50 : (cnt == 3 ? t85 : t95);
-                bool f = (mh < hz1) && (ma >= thr);                    // utils.py:20-33
-                if (p.rule == BPP_RULE_SPACE) {                        // space.py:122-125: sc >= 3
-                    const int rm = max(max(r00, r10), max(r01, r11));
-                    f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
-                }
-                me[rot * A + i * L + j] = f ? 1 : 0;
-                any |= __ballot(f);
-            }
+            };
+            using T = std::true_type;
+            using F = std::false_type;
+            if (fresh)
+                run(F{}, T{});
+            else if (big)
+                run(T{}, F{});
+            else
+                run(F{}, F{});
         }
         if (any != 0ull && lane == 0) rec[el].any = 1u;
     }
