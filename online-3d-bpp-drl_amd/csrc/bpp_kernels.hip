@@ -1505,17 +1505,30 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     return l;
 }
 
+template <int W, int L, int K, bool ROT, int MODE>
+void launch_fast_rot(const Launch &l, hipStream_t s) {
+    auto kern = bpp_fast_kernel<W, L, K, ROT, MODE>;
+    if (l.lds > 64 * 1024) {  // large workgroups: opt in to more than 64 KiB of dynamic LDS (once per kernel)
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
+}
+
 template <int W, int L, int K, int MODE>
 void launch_fast(const Launch &l, hipStream_t s) {
     if (l.p.rotation)
-        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, true, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
+        launch_fast_rot<W, L, K, true, MODE>(l, s);
     else
-        hipLaunchKernelGGL((bpp_fast_kernel<W, L, K, false, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
+        launch_fast_rot<W, L, K, false, MODE>(l, s);
 }
 
 template <int MODE>
 int launch(const Launch &l, hipStream_t s) {
-    if (l.lds > 64 * 1024) return fail(BPP_E_TOOLARGE, "LDS request above 64 KiB per block");
+    if (l.lds > (l.fast >= 0 ? 160 : 64) * 1024) return fail(BPP_E_TOOLARGE, "LDS request per workgroup too large");
     if (l.fast == 0)
         launch_fast<10, 10, 1, MODE>(l, s);
     else if (l.fast == 1)
