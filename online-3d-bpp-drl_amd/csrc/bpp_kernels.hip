@@ -148,7 +148,8 @@ __device__ __forceinline__ Win scan_window(const uint8_t *hm, int L, int lx, int
 }
 
 // Integer form of the float64 tests `max_area/area > 0.95 / 0.85 / 0.50` (exhaustively
-// equal for 1 <= max_area <= area <= 1600; tests/test_threshold_rewrite.py re-proves it up to 1024*... ).
+// equal for 1 <= max_area <= area <= 1600; tests/test_host_logic.py::test_threshold_integer_rewrite_is_exact
+// re-proves it for every window the kernels accept).
 // Rule U: acktr/utils.py:20-33.  Rule S (envs/bpp0/space.py:122-142) == rule U && sc >= 3, because when
 // the corner maximum rm equals max_h the two corner counts coincide and otherwise c == 0 in rule U.
 __device__ __forceinline__ bool feasible(const Win &w, int area, int z, int H, int rule) {
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // A workgroup owns wpb * epw (<= 64) consecutive bins.  Wave 0 carries one bin per lane through the
     // scalar chain (state, action, items, placement rule, reward, Monitor, next item) and leaves a
     // record per bin in the owning wave's LDS area; the other waves wait at the barrier.  (Executing
-    // this chain in every wave for only `epw` bins cost 45 % of the kernel.)
+    // this chain redundantly in every wave, for only `epw` bins each, cost ~4x the VALU work of this phase.)
     bool fin = false;
     double fin_ret = 0.0, fin_ratio = 0.0;
     int fin_len = 0;
