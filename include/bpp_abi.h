@@ -155,6 +155,16 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
 int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
                    int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream);
 
+/* Host-side CUT-2 item-sequence generator, multithreaded.  Restates
+ * envs/bpp0/mdCreator.py:59-166 (Box.benchmark_split, bin.gen_benchmark incl. its iterate-while-mutating
+ * list walk, depart_box) and draws from an exact re-implementation of CPython's `random.Random(seed)`
+ * (MT19937, init_by_array, getrandbits-based randbelow), so sequence k equals what the reference's
+ * MDlayerBoxCreator produces under random.seed(seed0 + k).  pool: HOST buffer [n][T][4] uint8, rows padded
+ * with the terminator (W,L,H).  Returns 0, or BPP_E_TOOLARGE when a sequence does not fit in T-1 entries
+ * (lengths[k] always receives the true length).  Both libraries export it; no GPU is involved. */
+int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
+                 int32_t bound_lo, int32_t bound_hi, uint64_t seed0, int32_t threads);
+
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }
  * on `stream` from one host call.  out->mask must hold the mask of the current observations (as left

@@ -1,0 +1,148 @@
+/* bpp_gen.inl -- shared host implementation of bpp_gen_cut2 (include/bpp_abi.h); included by both
+ * csrc/bpp_kernels.hip and oracle/bpp_oracle.c so the two libraries export the same generator.
+ * Plain C99-compatible code (also valid C++). */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- CPython's random.Random: MT19937 (Modules/_randommodule.c) ---------------------------------- */
+typedef struct { uint32_t mt[624]; int idx; } bpp_mt;
+
+static void bpp_mt_init_genrand(bpp_mt *r, uint32_t s) {
+    r->mt[0] = s;
+    for (int i = 1; i < 624; ++i) r->mt[i] = 1812433253u * (r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) + (uint32_t)i;
+    r->idx = 624;
+}
+
+/* random.seed(int): init_by_array over the 32-bit little-endian digits of abs(seed) */
+static void bpp_mt_seed(bpp_mt *r, uint64_t seed) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int klen = key[1] ? 2 : 1;
+    bpp_mt_init_genrand(r, 19650218u);
+    int i = 1, j = 0;
+    for (int k = 624 > klen ? 624 : klen; k; --k) {
+        r->mt[i] = (r->mt[i] ^ ((r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        if (++i >= 624) { r->mt[0] = r->mt[623]; i = 1; }
+        if (++j >= klen) j = 0;
+    }
+    for (int k = 623; k; --k) {
+        r->mt[i] = (r->mt[i] ^ ((r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        if (++i >= 624) { r->mt[0] = r->mt[623]; i = 1; }
+    }
+    r->mt[0] = 0x80000000u;
+    r->idx = 624;
+}
+
+static uint32_t bpp_mt_u32(bpp_mt *r) {
+    if (r->idx >= 624) {
+        uint32_t *mt = r->mt;
+        for (int k = 0; k < 624; ++k) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        r->idx = 0;
+    }
+    uint32_t y = r->mt[r->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* Random._randbelow_with_getrandbits(n), 0 < n < 2^32 */
+static uint32_t bpp_mt_below(bpp_mt *r, uint32_t n) {
+    int k = 0;
+    for (uint32_t v = n; v; v >>= 1) ++k;
+    uint32_t x = bpp_mt_u32(r) >> (32 - k);
+    while (x >= n) x = bpp_mt_u32(r) >> (32 - k);
+    return x;
+}
+
+/* ---- envs/bpp0/mdCreator.py:59-166 ---------------------------------------------------------------- */
+typedef struct { int x, y, z, low, high; } bpp_cut;
+
+static int bpp_cmp_low(const void *a, const void *b) {  /* stable sort by low_bound: tie -> original order */
+    const bpp_cut *p = (const bpp_cut *)a, *q = (const bpp_cut *)b;
+    if (p->low != q->low) return p->low < q->low ? -1 : 1;
+    return p->high < q->high ? -1 : (p->high > q->high ? 1 : 0);  /* `high` temporarily holds the original index */
+}
+
+/* returns the number of items; writes at most cap of them */
+static int bpp_cut2_sequence(int W, int L, int H, int lo, int hi, uint64_t seed, uint8_t *out, int cap) {
+    int vol = W * L * H, maxn = vol / (lo * lo * lo) + 8;
+    bpp_cut *valid = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn);
+    bpp_cut *inv = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn * 2);
+    int nv = 0, ni = 0;
+    bpp_mt rng;
+    bpp_mt_seed(&rng, seed);
+    inv[ni++] = (bpp_cut){W, L, H, 0, H};
+    while (ni) {
+        int i = 0;
+        while (i < ni) {                        /* `for box in invalid_box` with remove/append inside, :121-130 */
+            bpp_cut b = inv[i++];
+            int flags[3], nf = 0;               /* :60-66 */
+            if (b.x > hi) flags[nf++] = 0;
+            if (b.y > hi) flags[nf++] = 1;
+            if (b.z > hi) flags[nf++] = 2;
+            int f = flags[bpp_mt_below(&rng, (uint32_t)nf)];   /* random.choice, :68 */
+            bpp_cut s1, s2;
+            if (f == 0) {                       /* :70-79 */
+                if (b.x <= lo) continue;
+                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.x);   /* random.randint(1, x) */
+                if (r < lo || b.x - r < lo) continue;
+                s1 = (bpp_cut){r, b.y, b.z, b.low, b.high};
+                s2 = (bpp_cut){b.x - r, b.y, b.z, b.low, b.high};
+            } else if (f == 1) {                /* :80-89 */
+                if (b.y < lo) continue;
+                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.y);
+                if (r < lo || b.y - r < lo) continue;
+                s1 = (bpp_cut){b.x, r, b.z, b.low, b.high};
+                s2 = (bpp_cut){b.x, b.y - r, b.z, b.low, b.high};
+            } else {                            /* :90-99 */
+                if (b.z < lo) continue;
+                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.z);
+                if (r < lo || b.z - r < lo) continue;
+                s1 = (bpp_cut){b.x, b.y, b.z - r, b.low, b.high - r};
+                s2 = (bpp_cut){b.x, b.y, r, b.high - r, b.high};
+            }
+            memmove(inv + i - 1, inv + i, sizeof(bpp_cut) * (size_t)(ni - i));   /* invalid_box.remove(box) */
+            --ni;
+            bpp_cut subs[2] = {s1, s2};
+            for (int k = 0; k < 2; ++k) {
+                bpp_cut c = subs[k];
+                int ok = c.x >= lo && c.x <= hi && c.y >= lo && c.y <= hi && c.z >= lo && c.z <= hi;
+                if (ok) valid[nv++] = c; else inv[ni++] = c;
+            }
+        }
+    }
+    for (int k = 0; k < nv; ++k) valid[k].high = k;   /* depart_box: stable sort by low_bound, :137-138 */
+    qsort(valid, (size_t)nv, sizeof(bpp_cut), bpp_cmp_low);
+    for (int k = 0; k < nv && k < cap; ++k) {
+        out[4 * k] = (uint8_t)valid[k].x;
+        out[4 * k + 1] = (uint8_t)valid[k].y;
+        out[4 * k + 2] = (uint8_t)valid[k].z;
+        out[4 * k + 3] = 0;
+    }
+    free(valid);
+    free(inv);
+    return nv;
+}
+
+static int bpp_gen_cut2_range(uint8_t *pool, int32_t *lengths, int k0, int k1, int T, int W, int L, int H, int lo, int hi,
+                              uint64_t seed0) {
+    int overflow = 0;
+    for (int k = k0; k < k1; ++k) {
+        uint8_t *row = pool + (size_t)k * T * 4;
+        for (int t = 0; t < T; ++t) {
+            row[4 * t] = (uint8_t)W;
+            row[4 * t + 1] = (uint8_t)L;
+            row[4 * t + 2] = (uint8_t)H;
+            row[4 * t + 3] = 0;
+        }
+        int n = bpp_cut2_sequence(W, L, H, lo, hi, seed0 + (uint64_t)k, row, T - 1);
+        if (lengths) lengths[k] = n;
+        if (n > T - 1) overflow = 1;
+    }
+    return overflow;
+}

@@ -19,7 +19,7 @@ RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
-           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act"]
+           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2"]
 
 
 class Batch(ctypes.Structure):
@@ -94,6 +94,7 @@ def lib():
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         if L.bpp_abi_version() != ABI_VERSION:
             raise RuntimeError("libbpp_hip.so ABI version %d != %d" % (L.bpp_abi_version(), ABI_VERSION))

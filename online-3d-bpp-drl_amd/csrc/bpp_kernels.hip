@@ -27,6 +27,10 @@
 #include <type_traits>
 
 #include "../../include/bpp_abi.h"
+#include "../../include/bpp_gen.inl"
+
+#include <thread>
+#include <vector>
 
 #pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
 
@@ -1675,6 +1679,26 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, int32_t bound_lo,
+                 int32_t bound_hi, uint64_t seed0, int32_t threads) {
+    if (!pool || n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || bound_lo < 1 ||
+        bound_hi < 2 * bound_lo - 1)
+        return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument");
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
+    if (nt > n) nt = n;
+    std::vector<int> over((size_t)nt, 0);
+    std::vector<std::thread> pool_threads;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = (int)((int64_t)n * t / nt), k1 = (int)((int64_t)n * (t + 1) / nt);
+        pool_threads.emplace_back([=, &over] { over[(size_t)t] = bpp_gen_cut2_range(pool, lengths, k0, k1, T, W, L, H, bound_lo, bound_hi, seed0); });
+    }
+    for (auto &th : pool_threads) th.join();
+    for (int t = 0; t < nt; ++t)
+        if (over[(size_t)t]) return fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries");
+    return 0;
 }
 
 int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,

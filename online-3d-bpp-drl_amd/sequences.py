@@ -101,10 +101,35 @@ def cut2_sequence(container_size, bound, rng):
     return [(c.x, c.y, c.z) for c in valid]
 
 
-def cut2_pool(container_size, n, seed=0, bound=(2, 5), T=None):
-    """P = n CUT-2 sequences, sequence k drawn from random.Random(seed + k)."""
+def cut2_pool(container_size, n, seed=0, bound=(2, 5), T=None, native=True, threads=0):
+    """P = n CUT-2 sequences, sequence k drawn from random.Random(seed + k).  `native=True` runs the
+    multithreaded C++ generator of the library (bpp_gen_cut2, bit-identical output: it re-implements CPython's
+    MT19937 stream); `native=False` is the pure-Python restatement above."""
+    if native:
+        try:
+            return _cut2_pool_native(container_size, n, seed, bound, T, threads)
+        except (OSError, RuntimeError, AttributeError):
+            pass                      # library not built (e.g. docs tooling): same result from Python
     seqs = [cut2_sequence(container_size, bound, random.Random(seed + k)) for k in range(n)]
     return pad_pool(seqs, container_size, T)
+
+
+def _cut2_pool_native(container_size, n, seed, bound, T, threads):
+    import ctypes
+    from . import _lib
+    W, L, H = (int(v) for v in container_size)
+    lo, hi = (int(v) for v in bound)
+    lib = _lib.lib()
+    cap = T if T is not None else W * L * H // (lo ** 3) + 2          # upper bound on items + terminator
+    pool = np.zeros((n, cap, 4), np.uint8)
+    lengths = np.zeros(n, np.int32)
+    rc = lib.bpp_gen_cut2(pool.ctypes.data, lengths.ctypes.data, n, cap, W, L, H, lo, hi, int(seed), int(threads))
+    if rc == -2 and T is not None:
+        raise ValueError("a sequence has %d items, pool rows hold %d + terminator" % (int(lengths.max()), T - 1))
+    _lib.check(rc)
+    if T is None:
+        pool = np.ascontiguousarray(pool[:, :int(lengths.max()) + 1])
+    return pool
 
 
 class _Meta(object):

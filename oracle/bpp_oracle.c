@@ -15,6 +15,7 @@
  * validates those rewrites.  Paths below are relative to the reference root.
  */
 #include "../include/bpp_abi.h"
+#include "../include/bpp_gen.inl"
 
 #include <math.h>
 #include <stdio.h>
@@ -435,4 +436,14 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
         }
     }
     return 0;
+}
+
+int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
+                 int32_t bound_lo, int32_t bound_hi, uint64_t seed0, int32_t threads) {
+    (void)threads;
+    if (!pool || n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || bound_lo < 1 ||
+        bound_hi < 2 * bound_lo - 1)
+        return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument");
+    return bpp_gen_cut2_range(pool, lengths, 0, n, T, W, L, H, bound_lo, bound_hi, seed0)
+               ? fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries") : 0;
 }

@@ -88,3 +88,24 @@ def test_lazy_infos_match_reference_dict_shape():
     assert ["episode" in i for i in infos] == [False, True, False]
     assert infos.done_indices().tolist() == [1]
     assert infos[-1]["counter"] == 0
+
+
+@pytest.mark.parametrize("size,bound,seed", [((10, 10, 10), (2, 5), 0), ((20, 20, 20), (2, 5), 7), ((8, 12, 10), (2, 4), 123),
+                                              ((10, 10, 10), (2, 5), (1 << 32) + 5), ((10, 10, 10), (1, 3), 9)])
+def test_native_cut2_generator_equals_python_generator(size, bound, seed):
+    """bpp_gen_cut2 (C++, multithreaded, own MT19937) == the pure-Python restatement, which in turn equals the
+    reference's MDlayerBoxCreator under random.seed (tests/test_sequences_vs_reference.py): same items, same
+    order, for every sequence; seeds above 2^32 exercise the two-word init_by_array key."""
+    n = 40
+    a = sequences.cut2_pool(size, n, seed=seed, bound=bound, native=True, threads=3)
+    b = sequences.cut2_pool(size, n, seed=seed, bound=bound, native=False)
+    assert a.shape == b.shape and np.array_equal(a, b)
+    # the oracle library exports the same entry point (single-threaded build of the same source)
+    import ctypes
+    from oracle import oracle as orc
+    pool = np.zeros_like(a)
+    lengths = np.zeros(n, np.int32)
+    assert orc.lib().bpp_gen_cut2(pool.ctypes.data, lengths.ctypes.data, n, a.shape[1], *size, bound[0], bound[1], seed, 1) == 0
+    assert np.array_equal(pool, a) and lengths.max() == a.shape[1] - 1
+    with pytest.raises(ValueError):
+        sequences.cut2_pool(size, 4, seed=seed, bound=bound, T=5)
