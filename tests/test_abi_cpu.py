@@ -23,7 +23,7 @@ def lib():
 def header_functions():
     src = open(os.path.join(ROOT, "include", "bpp_abi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(bpp_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(bpp_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported(lib):
