@@ -24,6 +24,9 @@ def test_cut2_generator_is_rng_exact(size, n):
             cr.reset()
             ref = [tuple(b) for b in cr.box_set[:-1]]
             assert sequences.cut2_sequence(size, (2, 5), random.Random(1000 + s)) == ref
+            native = sequences.cut2_pool(size, 1, seed=1000 + s, native=True)[0]      # C++ generator, own MT19937
+            assert [tuple(int(v) for v in it[:3]) for it in native[:len(ref)]] == ref
+            assert tuple(int(v) for v in native[len(ref), :3]) == tuple(size)
 
 
 @pytest.mark.parametrize("size,rot,n", [((10, 10, 10), False, 40), ((10, 10, 10), True, 20), ((20, 20, 20), False, 4)])
