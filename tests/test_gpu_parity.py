@@ -418,3 +418,15 @@ def test_gpu_config0_shape_rs_16_envs_through_the_factory(bpp, oracle):
         np.testing.assert_array_equal(done, o["done"].astype(bool))
         rmask = o["mask"]
     assert len(episode_rewards) > 20
+
+
+def test_gpu_example_policy_in_the_loop_runs():
+    """examples/rollout_with_policy.py: CNN policy -> bpp_masked_act -> step_tensors -> EpisodeStats, end to end."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "rollout_with_policy.py"), "--envs", "512",
+                          "--steps", "12", "--rotation"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "policy in the loop" in out.stdout and "episodes" in out.stdout
