@@ -430,3 +430,18 @@ def test_gpu_example_policy_in_the_loop_runs():
                           "--steps", "12", "--rotation"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "policy in the loop" in out.stdout and "episodes" in out.stdout
+
+
+@pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
+def test_gpu_tuning_knobs_do_not_change_results(bpp, monkeypatch, epw, wpb):
+    """Every bins-per-wave / waves-per-workgroup setting (incl. workgroups above 64 KiB of LDS and a wave
+    serving 64 bins) replays the reference's golden rollouts bit for bit, with and without XCD remapping."""
+    monkeypatch.setenv("BPP_EPW", str(epw))
+    monkeypatch.setenv("BPP_WPB", str(wpb))
+    monkeypatch.setenv("BPP_XCD", str((epw + wpb) & 1))
+    for case in ("rollout_cut2_10_rot", "rollout_cut2_20", "rollout_wide_8x12x9_rot"):
+        g = load_golden(case)
+        size = tuple(int(v) for v in g["size"])
+        if epw * (size[0] * size[1] * (2 + int(g["rotation"])) + 48 + (size[0] + 1) * (size[1] + 1) * 16) * wpb > 150 * 1024:
+            continue      # would not fit the 160 KiB of LDS per workgroup: the library refuses, nothing to compare
+        check_rollout(lambda pool, sz, rot, E, rule: GpuEnv(bpp, pool, sz, rot, E, rule), g)
