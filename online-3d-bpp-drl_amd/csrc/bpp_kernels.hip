@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
             auto run = [&](auto big_c, auto empty_c) {
                 constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
+#pragma unroll 2
                 for (int t = lane; t < nv; t += kWave) {
                     const int i = (int)(((uint32_t)t * od) >> 16), j = t - i * nj;
                     bool f;
