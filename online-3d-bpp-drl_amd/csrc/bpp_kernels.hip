@@ -70,6 +70,7 @@ struct Params {
     int32_t xcd_remap;     // 1: XCD-aware block -> bins mapping
     int32_t ablate;        // profiling aid (BPP_ABLATE bit mask): skip a phase to read its cost; results are then wrong
     FastDiv divL, divA, divM, divA4;  // divA4: by A/4 (vector path) or A (scalar path) -> plane index
+    FastDiv divW, divM4, divPWW;      // runtime-geometry fast path: by W, M/4 and (L+1)+W
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
     double binvol;
@@ -673,8 +674,7 @@ struct __attribute__((aligned(16))) OriRec {
     uint32_t d;
 };
 
-template <int W, int L>
-__device__ __forceinline__ OriRec make_ori(int x, int y, int z, int H) {
+__device__ __forceinline__ OriRec make_ori(int W, int L, int x, int y, int z, int H) {
     OriRec o;
     const int area = x * y;
     const uint32_t valid = (x >= 1 && y >= 1 && x <= W && y <= L) ? 1u : 0u;
@@ -689,8 +689,17 @@ __device__ __forceinline__ OriRec make_ori(int x, int y, int z, int H) {
 
 template <int W, int L, int K, bool ROT, int MODE>
 __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel(const Params p) {
-    constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, PW = L + 1, PN = (W + 1) * (L + 1);
-    static_assert(A % 4 == 0, "fast path needs W*L % 4 == 0");
+    // W == 0 selects the runtime-geometry instantiation: sizes come from the launch parameters and the
+    // divisions below use their precomputed magic numbers; with W, L > 0 everything folds to constants.
+    constexpr bool RT = (W == 0);
+    static_assert(RT || (W * L) % 4 == 0, "fast path needs W*L % 4 == 0");
+    const int Wv = RT ? p.W : W, Lv = RT ? p.L : L;
+    const int A = Wv * Lv, A4 = A / 4, M = ROT ? 2 * A : A, M4 = M / 4, PW = Lv + 1, PN = (Wv + 1) * (Lv + 1);
+    auto div_a4 = [&](int n) { return RT ? (int)p.divA4.div((uint32_t)n) : n / A4; };
+    auto div_m4 = [&](int n) { return RT ? (int)p.divM4.div((uint32_t)n) : n / M4; };
+    auto div_l = [&](int n) { return RT ? (int)p.divL.div((uint32_t)n) : n / Lv; };
+    auto div_w = [&](int n) { return RT ? (int)p.divW.div((uint32_t)n) : n / Wv; };
+    auto div_pww = [&](int n) { return RT ? (int)p.divPWW.div((uint32_t)n) : n / (PW + Wv); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = threadIdx.x >> 6;
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         }
     } else if (MODE == kMaskObs) {
         for (int q = lane; q < nenv * A4; q += kWave) {
-            const int el = q / A4;
+            const int el = div_a4(q);
             const float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * A4];
             hm32[q] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
                       (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
@@ -779,16 +788,16 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const bool flag = ROT && idx > A;
             if (flag) idx -= A;
             const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
-            bool ok = active && idx >= 0 && idx < (int64_t)(W + 1) * L;
+            bool ok = active && idx >= 0 && idx < (int64_t)(Wv + 1) * Lv;
             int lx = 0, ly = 0;
             if (ok) {
-                lx = (int)((uint32_t)idx / (uint32_t)L);               // space.py:153-156
-                ly = (int)idx - lx * L;
-                ok = (lx + x <= W) && (ly + y <= L);                   // space.py:112-115
+                lx = div_l((int)idx);                                  // space.py:153-156
+                ly = (int)idx - lx * Lv;
+                ok = (lx + x <= Wv) && (ly + y <= Lv);                 // space.py:112-115
             }
             int top = 0;
             if (ok) {
-                const uint8_t *hb = ohm + lx * L + ly;
+                const uint8_t *hb = ohm + lx * Lv + ly;
                 int mh = 0, ma = 0;                                    // space.py:127-129
                 if (x <= 5 && y <= 5) {
                     // common item sizes: 25 predicated independent LDS reads instead of a divergent loop
@@ -796,7 +805,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
 #pragma unroll
                     for (int a = 0; a < 5; ++a)
 #pragma unroll
-                        for (int b = 0; b < 5; ++b) v[a][b] = (a < x && b < y) ? (int)hb[a * L + b] : -1;
+                        for (int b = 0; b < 5; ++b) v[a][b] = (a < x && b < y) ? (int)hb[a * Lv + b] : -1;
 #pragma unroll
                     for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -808,12 +817,12 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 } else {
                     for (int a = 0; a < x; ++a)
                         for (int b = 0; b < y; ++b) {
-                            const int v = hb[a * L + b];
+                            const int v = hb[a * Lv + b];
                             ma = v > mh ? 1 : ma + (v == mh);
                             mh = max(mh, v);
                         }
                 }
-                const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
+                const int r00 = hb[0], r10 = hb[(x - 1) * Lv], r01 = hb[y - 1], r11 = hb[(x - 1) * Lv + y - 1];
                 const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125
                 Win w;
                 w.mh = mh;
@@ -900,8 +909,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             ((BinRec *)(ob + p.off_rec))[oel] = r;
             OriRec *oo = (OriRec *)(ob + p.off_ori) + oel * 2;
             const int nx = r.item & 255u, ny = (r.item >> 8) & 255u, nz = (r.item >> 16) & 255u;
-            oo[0] = make_ori<W, L>(nx, ny, nz, p.H);
-            if (ROT) oo[1] = make_ori<W, L>(ny, nx, nz, p.H);          // utils.py:81-84
+            oo[0] = make_ori(Wv, Lv, nx, ny, nz, p.H);
+            if (ROT) oo[1] = make_ori(Wv, Lv, ny, nx, nz, p.H);          // utils.py:81-84
         }
     }
     __syncthreads();
@@ -918,10 +927,10 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const BinRec r = rec[el];
             if (r.flags & 1u) {
                 const int lx = r.place & 255u, ly = (r.place >> 8) & 255u, x = (r.place >> 16) & 255u, y = r.place >> 24;
-                uint8_t *hb = hm + el * A + lx * L + ly;
+                uint8_t *hb = hm + el * A + lx * Lv + ly;
                 const uint8_t top = (uint8_t)(r.flags >> 8);
                 for (int a = sl; a < x; a += G)
-                    for (int b = 0; b < y; ++b) hb[a * L + b] = top;
+                    for (int b = 0; b < y; ++b) hb[a * Lv + b] = top;
             }
         }
         wave_sync();
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         uint32_t *gh = (uint32_t *)(p.hmap + (size_t)e0 * A);
         float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
         for (int q = lane; q < nenv * A4; q += kWave) {
-            const int el = q / A4;
+            const int el = div_a4(q);
             const uint32_t v = hm32[q];
             gh[q] = v;
             go[q + el * (3 * A4)] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
@@ -955,7 +964,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
         if (MODE == kStep) {
             // ---- phase 3a: finished bins restart from an empty map --------------------------------
             for (int q = lane; q < nenv * A4; q += kWave)
-                if (rec[q / A4].flags & 2u) hm32[q] = 0u;
+                if (rec[div_a4(q)].flags & 2u) hm32[q] = 0u;
             wave_sync();
         }
         // ---- phase 3b: byte heightmap (state) + float32 observation out (bin3D.py:49-66) ----------
@@ -964,47 +973,70 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
 
     // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
-    if (!BPP_ABL(p, 1) && p.epw == 1 && W * 2 <= kWave) {
-        if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
-    } else if (!BPP_ABL(p, 1)) {
+    bool built = false;
+    if constexpr (!RT) {
+        if (!BPP_ABL(p, 1) && p.epw == 1 && W * 2 <= kWave) {
+            if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
+            built = true;
+        }
+    }
+    if (!built && !BPP_ABL(p, 1)) {
         Ent<K> zero;
 #pragma unroll
         for (int k = 0; k < K; ++k) zero.w[k] = 0;
-        for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
-            const int el = t / (PW + W), r = t - el * (PW + W);
+        for (int t = lane; t < nenv * (PW + Wv); t += kWave) {         // row 0 and column 0
+            const int el = div_pww(t), r = t - el * (PW + Wv);
             P[el * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
         }
-        for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
-            const int el = t / W, i = t - el * W;
-            const uint8_t *row = hm + el * A + i * L;
-            uint32_t hv[L];
-#pragma unroll
-            for (int j = 0; j < L; ++j) hv[j] = row[j];
+        for (int t = lane; t < nenv * Wv; t += kWave) {                // running sums along each row
+            const int el = div_w(t), i = t - el * Wv;
+            const uint8_t *row = hm + el * A + i * Lv;
             Ent<K> *pr = P + el * PN + (i + 1) * PW + 1;
             Ent<K> s = zero;
+            if constexpr (!RT) {
+                uint32_t hv[L > 0 ? L : 1];
 #pragma unroll
-            for (int j = 0; j < L; ++j) {
-                const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+                for (int j = 0; j < L; ++j) hv[j] = row[j];
 #pragma unroll
-                for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
-                pr[j] = s;
+                for (int j = 0; j < L; ++j) {
+                    const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                    pr[j] = s;
+                }
+            } else {
+                for (int j = 0; j < Lv; ++j) {
+                    const Ent<K> c = code_of<K>(min((uint32_t)row[j], hclamp));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                    pr[j] = s;
+                }
             }
         }
         wave_sync();
-        for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
-            const int el = t / L, j = t - el * L;
+        for (int t = lane; t < nenv * Lv; t += kWave) {                // then down each column
+            const int el = div_l(t), j = t - el * Lv;
             Ent<K> *pc = P + el * PN + PW + (j + 1);
             Ent<K> s = zero;
-            constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
-            for (int i0 = 0; i0 < W; i0 += CH) {
-                Ent<K> v[CH];
+            if constexpr (!RT) {
+                constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
+                for (int i0 = 0; i0 < W; i0 += CH) {
+                    Ent<K> v[CH];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
+                    for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
+                    for (int i = 0; i < CH; ++i) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
-                    pc[(i0 + i) * PW] = s;
+                        for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
+                        pc[(i0 + i) * PW] = s;
+                    }
+                }
+            } else {
+                for (int i = 0; i < Wv; ++i) {
+                    const Ent<K> v = pc[i * PW];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) s.w[k] += v.w[k];
+                    pc[i * PW] = s;
                 }
             }
         }
@@ -1015,7 +1047,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // Bin-uniform evaluation: the wave walks its bins (and orientations) one after the other, so the
     // item constants live in scalar registers, and only the (W-x+1)*(L-y+1) in-range candidates
     // (utils.py:54-55 loop ranges) are enumerated -- lane t <-> (i, j) = (t / nj, t % nj).
-    for (int g = lane; g < nenv * (M / 4); g += kWave) ((uint32_t *)mk)[g] = 0u;
+    for (int g = lane; g < nenv * M4; g += kWave) ((uint32_t *)mk)[g] = 0u;
     wave_sync();
     for (int el = 0; el < (BPP_ABL(p, 2) ? 0 : nenv); ++el) {
         unsigned long long any = 0ull;
@@ -1040,7 +1072,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const bool big = (oa >> 25) & 1u;
             const int nj = (int)(oc >> 24) + 1, nv = ((int)((oc >> 16) & 255u) + 1) * nj;
             const int t95 = ob & 0xffffu, t85 = ob >> 16, t50 = oc & 0xffffu;
-            const int o10 = (x - 1) * L, o01 = y - 1;
+            const int o10 = (x - 1) * Lv, o01 = y - 1;
             // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
             auto run = [&](auto big_c, auto empty_c) {
                 constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
@@ -1062,7 +1094,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                         } else {
                             window_top<K>(Pe, PW, i, j, x, y, mh, ma);
                         }
-                        const uint8_t *hb = he + i * L + j;
+                        const uint8_t *hb = he + i * Lv + j;
                         const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
                         const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
                         const int thr = cnt == 4 ? t50 : (cnt == 3 ? t85 : t95);
@@ -1072,7 +1104,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                             f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
                         }
                     }
-                    me[rot * A + i * L + j] = f ? 1 : 0;
+                    me[rot * A + i * Lv + j] = f ? 1 : 0;
                     any |= __ballot(f);
                 }
             };
@@ -1095,7 +1127,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // from one multiply (bytes are 0/1), an inclusive scan inside the sub-group locates the lane holding
     // the pick-th set entry (pick = hash * count >> 32) and prefix-byte compares locate it in the dword.
     if (MODE == kStep && p.next_action != nullptr) {
-        constexpr int NQ = M / 4;
+        const int NQ = M4;
         const int G = kWave >> p.epw_shift;
         const int el = lane >> (6 - p.epw_shift), sl = lane & (G - 1);
         const bool act = el < nenv;
@@ -1138,8 +1170,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
     {
         float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
-        for (int g = lane; g < (BPP_ABL(p, 4) ? 0 : nenv * (M / 4)); g += kWave) {
-            const uint32_t v = rec[g / (M / 4)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
+        for (int g = lane; g < (BPP_ABL(p, 4) ? 0 : nenv * M4); g += kWave) {
+            const uint32_t v = rec[div_m4(g)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
             gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
         }
     }
@@ -1445,6 +1477,7 @@ struct FastGeo {
 };
 constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}, {10, 10, 2}};
 constexpr int kNumFastGeo = sizeof(kFastGeo) / sizeof(kFastGeo[0]);
+constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 
 Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     Launch l;
@@ -1472,7 +1505,14 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
                 l.fast = g;
                 break;
             }
-    const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * kFastGeo[l.fast].K : 0;
+    // any other bin whose area is a multiple of 4 and whose heights fit two histogram words runs the same
+    // algorithm with runtime geometry (kRuntimeGeo + K - 1)
+    int rt_k = 0;
+    if (!(gen && atoi(gen) != 0) && l.fast < 0 && l.vec && H + 2 <= kLevelsPerWord * 2) {
+        rt_k = H + 2 <= kLevelsPerWord ? 1 : 2;
+        l.fast = kRuntimeGeo + rt_k - 1;
+    }
+    const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * (rt_k ? rt_k : kFastGeo[l.fast].K) : 0;
     if (l.fast >= 0 && !(env && atoi(env) > 0)) {
         // prefix image dominates LDS: keep a 4-wave block under 24 KiB (>= 6 blocks = 24 waves per CU).
         // Measured on MI355X: 10x10: EPW=4 39 us vs 43 us at EPW=8 and 50 us at EPW=2; 10x10 + rotation
@@ -1500,6 +1540,9 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     p.divA = make_fastdiv(p.A);
     p.divM = make_fastdiv(p.M);
     p.divA4 = make_fastdiv(l.vec ? p.A / 4 : p.A);
+    p.divW = make_fastdiv(W);
+    p.divM4 = make_fastdiv(p.M / 4 > 0 ? p.M / 4 : 1);
+    p.divPWW = make_fastdiv(L + 1 + W);
     p.binvol = (double)W * (double)L * (double)H;
     const int waves = (E + epw - 1) / epw;
     l.wpb = kWavesPerBlock;
@@ -1543,6 +1586,10 @@ int launch(const Launch &l, hipStream_t s) {
         launch_fast<20, 20, 2, MODE>(l, s);
     else if (l.fast == 3)
         launch_fast<10, 10, 2, MODE>(l, s);
+    else if (l.fast == kRuntimeGeo)
+        launch_fast<0, 0, 1, MODE>(l, s);
+    else if (l.fast == kRuntimeGeo + 1)
+        launch_fast<0, 0, 2, MODE>(l, s);
     else if (l.vec)
         hipLaunchKernelGGL((bpp_kernel<true, MODE>), dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
     else
