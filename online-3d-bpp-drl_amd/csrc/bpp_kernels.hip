@@ -2,8 +2,10 @@
 // environment step (include/bpp_abi.h).  Hand-written for wave64; integer/indexing work, no MFMA.
 //
 // Two implementations of the same step share this file:
-//   * bpp_fast_kernel<W,L,K,ROT,MODE>  compile-time geometry (10x10, 20x20), the production path;
-//   * bpp_kernel<VEC,MODE>             any W*L <= 1024 (also W*L % 4 != 0), the fallback.
+//   * bpp_fast_kernel<W,L,K,ROT,MODE>  the production path: compile-time geometry for 10x10 and 20x20 bins,
+//                                      W = L = 0 instantiates the same code with runtime geometry for any
+//                                      other bin with W*L % 4 == 0 and H <= 22;
+//   * bpp_kernel<VEC,MODE>             any W*L <= 1024 (also W*L % 4 != 0, H up to 255), the fallback.
 // Work decomposition of the fast path:
 //   * a workgroup of 4 waves owns 4*EPW consecutive bins (EPW = 4 for the 10x10 bin, 1 for 20x20); the
 //     bins of a wave are contiguous in every tensor ([E][A] byte heightmap, [E][4A] observation, [E][M]
