@@ -530,7 +530,7 @@ __device__ __forceinline__ void top_of(const Ent<K> &h, int &m, int &cnt) {
         }
     const int msb = 63 - __builtin_clzll(v);
     const int lvl = (msb * 13) >> 6;  // msb / 5 for msb <= 63
-    cnt = (int)((v >> (kFieldBits * lvl)) & 31u);
+    cnt = (int)(v >> (kFieldBits * lvl));  // lvl is the top non-empty field: nothing above it to mask off
     m = word * kLevelsPerWord + lvl;
 }
 
