@@ -343,13 +343,31 @@ class BppVecEnv(object):
         return self.hmap.view(self.E, self.W, self.L).to(torch.int32)
 
     def state_dict(self):
-        """Env checkpoint (the reference never checkpoints env state; a handful of tensors here)."""
-        return {"hmap": self.hmap.clone(), "state": self.state.clone(), "first_reset": self._first_reset}
+        """Env checkpoint (the reference never checkpoints env state; a handful of tensors here): byte
+        heightmaps, per-bin records, statistics slots and -- so that a loop can resume mid-rollout -- the
+        last observation and its mask."""
+        sd = {"hmap": self.hmap.clone(), "state": self.state.clone(), "stats": self.stats_slots.clone(),
+              "first_reset": self._first_reset}
+        if self._bufs is not None:
+            sd["obs"] = self._bufs["obs"].clone()
+            if self._bufs["mask"] is not None:
+                sd["mask"] = self._bufs["mask"].clone()
+        return sd
 
     def load_state_dict(self, sd):
         self.hmap.copy_(sd["hmap"])
         self.state.copy_(sd["state"])
+        if "stats" in sd:
+            self.stats_slots.copy_(sd["stats"])
         self._first_reset = bool(sd["first_reset"])
+        if "obs" in sd:
+            bufs, _ = self._buffers()
+            if self._res is None or self.fresh_outputs:
+                self._res = StepTensors(**bufs)
+            bufs["obs"].copy_(sd["obs"])
+            if "mask" in sd and bufs["mask"] is not None:
+                bufs["mask"].copy_(sd["mask"])
+                self.location_masks = bufs["mask"]
 
     def state_numpy(self):
         """bpp_env_state[E] as a structured numpy array (tests)."""

@@ -445,3 +445,22 @@ def test_gpu_tuning_knobs_do_not_change_results(bpp, monkeypatch, epw, wpb):
         if epw * (size[0] * size[1] * (2 + int(g["rotation"])) + 48 + (size[0] + 1) * (size[1] + 1) * 16) * wpb > 150 * 1024:
             continue      # would not fit the 160 KiB of LDS per workgroup: the library refuses, nothing to compare
         check_rollout(lambda pool, sz, rot, E, rule: GpuEnv(bpp, pool, sz, rot, E, rule), g)
+
+
+def test_gpu_env_checkpoint_resume(bpp):
+    """state_dict()/load_state_dict(): the environment state is three tensors; resuming replays identically."""
+    import torch
+    size, E = (10, 10, 10), 700
+    pool = bpp.sequences.cut2_pool(size, 32, seed=4)
+    env = bpp.BppVecEnv(E, size, enable_rotation=True, pool=pool)
+    env.reset()
+    env.rollout_uniform(seed=3, step0=0, nsteps=9)
+    ckpt = env.state_dict()
+    first = env.rollout_uniform(seed=3, step0=9, nsteps=11)
+    want = {k: getattr(first, k).clone() for k in ("obs", "mask", "counter", "ratio", "ep_ret")}
+    other = bpp.BppVecEnv(E, size, enable_rotation=True, pool=pool)       # a fresh env object, never reset
+    other.load_state_dict(ckpt)
+    assert torch.equal(other.location_masks, ckpt["mask"])
+    again = other.rollout_uniform(seed=3, step0=9, nsteps=11)
+    for k, v in want.items():
+        assert torch.equal(getattr(again, k), v), k
