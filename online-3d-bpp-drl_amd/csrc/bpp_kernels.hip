@@ -120,6 +120,12 @@ __device__ __forceinline__ int xcd_block(int remap) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// Caller-supplied item sizes (mask-only entry points): each side is clamped into a byte so that it cannot
+// spill into its neighbour's field; a side above 255 is wider than any supported bin either way.
+__device__ __forceinline__ uint32_t pack_item(int x, int y, int z) {
+    return (uint32_t)min(max(x, 0), 255) | ((uint32_t)min(max(y, 0), 255) << 8) | ((uint32_t)min(max(z, 0), 255) << 16);
+}
+
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
     // accesses across the point where other lanes' data is consumed.
@@ -373,10 +379,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         } else if (MODE == kMaskObs) {
             // acktr/utils.py:43-45: x, y, z = int(plane[k][0])
             const float *o = p.obs_in + (size_t)e * 4 * A;
-            r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
+            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
         } else {
             const int32_t *it = p.items_in + (size_t)e * 3;
-            r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
+            r.item = pack_item(it[0], it[1], it[2]);
         }
         rec[lane] = r;
     }
@@ -902,10 +908,10 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             r.flags = 2u;
         } else if (MODE == kMaskObs) {
             const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
-            r.item = (uint32_t)(int)o[A] | ((uint32_t)(int)o[2 * A] << 8) | ((uint32_t)(int)o[3 * A] << 16);
+            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
         } else {
             const int32_t *it = p.items_in + (size_t)e * 3;
-            r.item = (uint32_t)it[0] | ((uint32_t)it[1] << 8) | ((uint32_t)it[2] << 16);
+            r.item = pack_item(it[0], it[1], it[2]);
         }
         if (active) {
             ((BinRec *)(ob + p.off_rec))[oel] = r;

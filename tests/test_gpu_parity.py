@@ -464,3 +464,14 @@ def test_gpu_env_checkpoint_resume(bpp):
     again = other.rollout_uniform(seed=3, step0=9, nsteps=11)
     for k, v in want.items():
         assert torch.equal(getattr(again, k), v), k
+
+
+def test_gpu_mask_entry_points_clamp_oversized_items(bpp, oracle):
+    """Items far wider than the bin (also beyond a byte) cannot fit anywhere: all-ones fallback, exactly like
+    the reference's empty loop ranges (acktr/utils.py:54-60)."""
+    size = (10, 10, 10)
+    hm = np.zeros((3, 100), np.int32)
+    items = np.array([[300, 2, 2], [2, 1000, 2], [3, 3, 3]], np.int32)
+    want = oracle.mask_from_hmap(hm, items, size, True, 0)
+    assert want[0].min() == 1 and want[1].min() == 1 and want[2].sum() == 128
+    np.testing.assert_array_equal(bpp.batched_mask_from_hmap(hm, items, size, True, "utils").cpu().numpy(), want)
