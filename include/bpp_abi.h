@@ -13,7 +13,8 @@
  *
  * Ownership: the caller allocates and owns every buffer (PyTorch-ROCm tensors in practice); the
  * library never allocates or frees device memory and keeps no global state besides the thread-local
- * last-error string.  Kernels are enqueued on `stream` and the calls return without synchronising.
+ * last-error string and the launch-shape knobs (bpp_knobs, which never change results).  Kernels are
+ * enqueued on `stream` and the calls return without synchronising.
  *
  * Error convention: 0 = success; >0 = hipError_t from the runtime; <0 = BPP_E_* below.  A message
  * is available from bpp_last_error().  An infeasible or out-of-range *action* is not an error: it
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 4
+#define BPP_ABI_VERSION 5
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -107,6 +108,21 @@ typedef struct bpp_step_out {
     uint64_t sample_seed;
     uint64_t sample_step;
 } bpp_step_out;
+
+/* Launch-shape tuning knobs of the step/reset/mask kernels (no reference counterpart).  Process-global;
+ * initialised once from the environment (BPP_EPW, BPP_WPB, BPP_XCD, BPP_FORCE_GENERIC, BPP_ABLATE) the first
+ * time they are needed, afterwards only bpp_set_knobs changes them -- a launch never reads the environment.
+ * Results never depend on them (tests/test_gpu_parity.py replays the golden rollouts under every setting). */
+typedef struct bpp_knobs {
+    int32_t bins_per_wave;    /* 0 = heuristic (10x10: 4, 20x20: 1); else 1..64 (rounded down to a power of two) */
+    int32_t waves_per_group;  /* 0 = default (4); else 1..16                                                    */
+    int32_t xcd_remap;        /* 1 = give every XCD one contiguous eighth of the bins (default), 0 = off        */
+    int32_t force_generic;    /* 1 = route every geometry through the generic cell-scan kernel                  */
+    int32_t ablate;           /* profiling builds only (-DBPP_ENABLE_ABLATION): phase bit mask, else ignored    */
+    int32_t reserved[3];
+} bpp_knobs;
+int bpp_get_knobs(bpp_knobs *out);
+int bpp_set_knobs(const bpp_knobs *k);
 
 int bpp_abi_version(void);
 const char *bpp_last_error(void);

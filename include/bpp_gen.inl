@@ -129,6 +129,17 @@ static int bpp_cut2_sequence(int W, int L, int H, int lo, int hi, uint64_t seed,
     return nv;
 }
 
+/* Arguments the reference itself cannot handle: a bin already inside the bounds, or with a side below
+ * the lower bound, makes Box.benchmark_split call random.choice([]) (IndexError, mdCreator.py:60-68);
+ * bound_hi < 2*bound_lo - 1 leaves pieces that can never be cut into range (endless loop, :117-135). */
+static int bpp_gen_cut2_args_ok(int n, int T, int W, int L, int H, int lo, int hi) {
+    if (n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255) return 0;
+    if (lo < 1 || hi < 2 * lo - 1) return 0;
+    if (W < lo || L < lo || H < lo) return 0;
+    if (W <= hi && L <= hi && H <= hi) return 0;
+    return 1;
+}
+
 static int bpp_gen_cut2_range(uint8_t *pool, int32_t *lengths, int k0, int k1, int T, int W, int L, int H, int lo, int hi,
                               uint64_t seed0) {
     int overflow = 0;

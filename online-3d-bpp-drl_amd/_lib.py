@@ -13,13 +13,14 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 LIB = os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
-           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2"]
+           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2",
+           "bpp_get_knobs", "bpp_set_knobs"]
 
 
 class Batch(ctypes.Structure):
@@ -36,6 +37,12 @@ class StepOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len",
                                                "next_action")] + [("sample_seed", ctypes.c_uint64),
                                                                   ("sample_step", ctypes.c_uint64)]
+
+
+class Knobs(ctypes.Structure):
+    """struct bpp_knobs"""
+    _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
+                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
 def hipcc():
@@ -96,6 +103,8 @@ def lib():
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_get_knobs.argtypes = [ctypes.POINTER(Knobs)]
+        L.bpp_set_knobs.argtypes = [ctypes.POINTER(Knobs)]
         if L.bpp_abi_version() != ABI_VERSION:
             raise RuntimeError("libbpp_hip.so ABI version %d != %d" % (L.bpp_abi_version(), ABI_VERSION))
         _lib = L
@@ -105,6 +114,27 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("libbpp_hip error %d: %s" % (rc, lib().bpp_last_error().decode()))
+
+
+def get_knobs():
+    """Current launch-shape knobs as a dict (include/bpp_abi.h: bpp_knobs)."""
+    k = Knobs()
+    check(lib().bpp_get_knobs(ctypes.byref(k)))
+    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate")}
+
+
+def set_knobs(**kw):
+    """Change launch-shape knobs for the whole process (results never depend on them); returns the previous
+    settings so a caller can restore them: `old = set_knobs(force_generic=1); ...; set_knobs(**old)`."""
+    old = get_knobs()
+    new = dict(old)
+    for name, v in kw.items():
+        if name not in new:
+            raise TypeError("unknown knob %r" % (name,))
+        new[name] = int(v)
+    k = Knobs(new["bins_per_wave"], new["waves_per_group"], new["xcd_remap"], new["force_generic"], new["ablate"])
+    check(lib().bpp_set_knobs(ctypes.byref(k)))
+    return old
 
 
 def limits():

@@ -31,6 +31,8 @@
 #include "../../include/bpp_abi.h"
 #include "../../include/bpp_gen.inl"
 
+#include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
         const int x = rot ? iy : ix, y = rot ? ix : iy;
         bool f = false;
-        if ((int)i + x <= p.W && (int)j + y <= L) {  // utils.py:54-55 loop ranges
+        if (x >= 1 && y >= 1 && (int)i + x <= p.W && (int)j + y <= L) {  // utils.py:54-55 loop ranges (a zero-sized side never fits, like the fast path)
             Win w = scan_window(hm + el * A, L, i, j, x, y);
             f = feasible(w, x * y, z, p.H, p.rule);
         }
@@ -675,6 +677,7 @@ __device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *
 // bin's lane and read (one ds_read_b128) by every candidate lane.  The float64 ratio tests of
 // acktr/utils.py:28-33 become integer thresholds on max_area:
 //   ma/area > 0.95  <=>  ma >= floor(19*area/20) + 1   (t95), likewise t85 (17/20) and t50 (1/2).
+constexpr int kCandShift = 22;  // candidate index decode, see make_ori
 struct __attribute__((aligned(16))) OriRec {
     uint32_t a;  // x | y<<8 | (max(H - z + 1, 0))<<16 (9 bits) | big<<25 | valid<<26
     uint32_t b;  // t95 | t85<<16
@@ -691,7 +694,9 @@ __device__ __forceinline__ OriRec make_ori(int W, int L, int x, int y, int z, in
     o.a = (uint32_t)x | ((uint32_t)y << 8) | (hz1 << 16) | (big << 25) | (valid << 26);
     o.b = (uint32_t)(19 * area / 20 + 1) | ((uint32_t)(17 * area / 20 + 1) << 16);
     o.c = (uint32_t)(area / 2 + 1) | ((uint32_t)((W - x) & 255) << 16) | ((uint32_t)((L - y) & 255) << 24);
-    o.d = (65536u + (uint32_t)(L - y + 1) - 1u) / (uint32_t)max(L - y + 1, 1);  // ceil(2^16 / nj): t / nj == (t * d) >> 16 for t < 1024
+    // ceil(2^22 / nj): t / nj == (t * d) >> 22 for every t < 1024, nj <= 256 (t * d < 2^32, d < 2^24: one
+    // full-rate 24-bit multiply; exhaustively checked in tests/test_host_logic.py)
+    o.d = ((1u << kCandShift) + (uint32_t)(L - y + 1) - 1u) / (uint32_t)max(L - y + 1, 1);
     return o;
 }
 
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
 #pragma unroll 2
                 for (int t = lane; t < nv; t += kWave) {
-                    const int i = (int)(((uint32_t)t * od) >> 16), j = t - i * nj;
+                    const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
                     bool f;
                     if (EMPTY) {
                         f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
@@ -1412,10 +1417,10 @@ __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, 
     }
 }
 
-// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.stats.
+// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.stats: grid-stride
+// partial sums, one wave reduction, four float64 atomics per wave that saw a finished episode.
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
                                                     const int32_t *ep_len, int E, double *acc) {
-    __shared__ double red[4][4];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
         const double f = done[e] ? 1.0 : 0.0;
@@ -1431,17 +1436,11 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const d
         s2 += __shfl_down(s2, d, kWave);
         s3 += __shfl_down(s3, d, kWave);
     }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        red[w][0] = s0;
-        red[w][1] = s1;
-        red[w][2] = s2;
-        red[w][3] = s3;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (v != 0.0) atomicAdd(acc + threadIdx.x, v);
+    if ((threadIdx.x & (kWave - 1)) == 0 && s3 != 0.0) {
+        atomicAdd(acc + 0, s0);
+        atomicAdd(acc + 1, s1);
+        atomicAdd(acc + 2, s2);
+        atomicAdd(acc + 3, s3);
     }
 }
 
@@ -1487,6 +1486,31 @@ constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}, {10, 10, 
 constexpr int kNumFastGeo = sizeof(kFastGeo) / sizeof(kFastGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 
+// Tuning knobs (include/bpp_abi.h: bpp_knobs).  Initialised ONCE per process from the environment
+// (BPP_EPW, BPP_WPB, BPP_XCD, BPP_FORCE_GENERIC, BPP_ABLATE), afterwards only bpp_set_knobs changes them:
+// a launch never looks at the environment.
+std::mutex g_knob_mutex;
+bpp_knobs g_knobs;
+bool g_knobs_init = false;
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+bpp_knobs current_knobs() {
+    std::lock_guard<std::mutex> lock(g_knob_mutex);
+    if (!g_knobs_init) {
+        g_knobs.bins_per_wave = env_int("BPP_EPW", 0);
+        g_knobs.waves_per_group = env_int("BPP_WPB", 0);
+        g_knobs.xcd_remap = env_int("BPP_XCD", 1);
+        g_knobs.force_generic = env_int("BPP_FORCE_GENERIC", 0);
+        g_knobs.ablate = env_int("BPP_ABLATE", 0);
+        g_knobs_init = true;
+    }
+    return g_knobs;
+}
+
 Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     Launch l;
     Params &p = l.p;
@@ -1500,14 +1524,14 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     p.M = p.A * (1 + rotation);
     p.rule = rule;
     l.vec = (p.A % 4) == 0;
+    const bpp_knobs kn = current_knobs();
     int epw = 16;
-    const char *env = getenv("BPP_EPW");
-    if (env && atoi(env) > 0) epw = atoi(env) > 64 ? 64 : atoi(env);
+    if (kn.bins_per_wave > 0) epw = kn.bins_per_wave > 64 ? 64 : kn.bins_per_wave;
     else
         while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16)) > 32 * 1024) epw >>= 1;
     l.fast = -1;
-    const char *gen = getenv("BPP_FORCE_GENERIC");
-    if (!(gen && atoi(gen) != 0))
+    const bool gen = kn.force_generic != 0;
+    if (!gen)
         for (int g = 0; g < kNumFastGeo; ++g)
             if (kFastGeo[g].W == W && kFastGeo[g].L == L && H + 2 <= kLevelsPerWord * kFastGeo[g].K) {
                 l.fast = g;
@@ -1516,12 +1540,12 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     // any other bin whose area is a multiple of 4 and whose heights fit two histogram words runs the same
     // algorithm with runtime geometry (kRuntimeGeo + K - 1)
     int rt_k = 0;
-    if (!(gen && atoi(gen) != 0) && l.fast < 0 && l.vec && H + 2 <= kLevelsPerWord * 2) {
+    if (!gen && l.fast < 0 && l.vec && H + 2 <= kLevelsPerWord * 2) {
         rt_k = H + 2 <= kLevelsPerWord ? 1 : 2;
         l.fast = kRuntimeGeo + rt_k - 1;
     }
     const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * (rt_k ? rt_k : kFastGeo[l.fast].K) : 0;
-    if (l.fast >= 0 && !(env && atoi(env) > 0)) {
+    if (l.fast >= 0 && kn.bins_per_wave <= 0) {
         // prefix image dominates LDS: keep a 4-wave block under 24 KiB (>= 6 blocks = 24 waves per CU).
         // Measured on MI355X: 10x10: EPW=4 39 us vs 43 us at EPW=8 and 50 us at EPW=2; 10x10 + rotation
         // (21 KiB at EPW=4): 51 us vs 59 us at EPW=2; 20x20: EPW=1 85 us vs 116 us at EPW=2.
@@ -1534,10 +1558,8 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
         epw = 1 << sh;
         p.epw_shift = sh;
     }
-    const char *xr = getenv("BPP_XCD");
-    p.xcd_remap = xr ? atoi(xr) : 1;
-    const char *ab = getenv("BPP_ABLATE");
-    p.ablate = ab ? atoi(ab) : 0;
+    p.xcd_remap = kn.xcd_remap;
+    p.ablate = kn.ablate;
     p.epw = epw;
     p.off_mk = (epw * p.A + 15) & ~15;
     p.off_rec = (p.off_mk + epw * p.M + 15) & ~15;
@@ -1554,8 +1576,8 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     p.binvol = (double)W * (double)L * (double)H;
     const int waves = (E + epw - 1) / epw;
     l.wpb = kWavesPerBlock;
-    const char *wpb = getenv("BPP_WPB");
-    if (wpb && atoi(wpb) >= 1 && atoi(wpb) <= (l.fast >= 0 ? kMaxFastWavesPerBlock : kWavesPerBlock)) l.wpb = atoi(wpb);
+    if (kn.waves_per_group >= 1 && kn.waves_per_group <= (l.fast >= 0 ? kMaxFastWavesPerBlock : kWavesPerBlock))
+        l.wpb = kn.waves_per_group;
     if (l.fast >= 0 && l.wpb * epw > kWave) l.wpb = kWave / epw;  // wave 0 carries one bin per lane
     l.blocks = (waves + l.wpb - 1) / l.wpb;
     l.lds = (size_t)l.wpb * p.lds_per_wave;
@@ -1565,11 +1587,14 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
 template <int W, int L, int K, bool ROT, int MODE>
 void launch_fast_rot(const Launch &l, hipStream_t s) {
     auto kern = bpp_fast_kernel<W, L, K, ROT, MODE>;
-    if (l.lds > 64 * 1024) {  // large workgroups: opt in to more than 64 KiB of dynamic LDS (once per kernel)
-        static bool raised = false;
-        if (!raised) {
+    if (l.lds > 64 * 1024) {  // large workgroups: opt in to more than 64 KiB of dynamic LDS, once per kernel AND device
+        static std::atomic<uint64_t> raised{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(raised.load(std::memory_order_acquire) & bit)) {
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
+            raised.fetch_or(bit, std::memory_order_release);
         }
     }
     hipLaunchKernelGGL(kern, dim3(l.blocks), dim3(kWave * l.wpb), l.lds, s, l.p);
@@ -1648,6 +1673,22 @@ extern "C" {
 int bpp_abi_version(void) { return BPP_ABI_VERSION; }
 
 const char *bpp_last_error(void) { return g_err; }
+
+int bpp_get_knobs(bpp_knobs *out) {
+    if (!out) return fail(BPP_E_BADARG, "bpp_get_knobs: NULL");
+    *out = current_knobs();
+    return 0;
+}
+
+int bpp_set_knobs(const bpp_knobs *k) {
+    if (!k) return fail(BPP_E_BADARG, "bpp_set_knobs: NULL");
+    if (k->bins_per_wave < 0 || k->bins_per_wave > 64 || k->waves_per_group < 0 || k->waves_per_group > kMaxFastWavesPerBlock)
+        return fail(BPP_E_BADARG, "bpp_set_knobs: bins_per_wave must be 0..64, waves_per_group 0..16");
+    (void)current_knobs();
+    std::lock_guard<std::mutex> lock(g_knob_mutex);
+    g_knobs = *k;
+    return 0;
+}
 
 int bpp_limits(int32_t out[2]) {
     if (!out) return fail(BPP_E_BADARG, "bpp_limits: NULL");
@@ -1739,9 +1780,8 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
 
 int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, int32_t bound_lo,
                  int32_t bound_hi, uint64_t seed0, int32_t threads) {
-    if (!pool || n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || bound_lo < 1 ||
-        bound_hi < 2 * bound_lo - 1)
-        return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument");
+    if (!pool || !bpp_gen_cut2_args_ok(n, T, W, L, H, bound_lo, bound_hi))
+        return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument (bin must exceed bound_hi on some side and bound_lo on none)");
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
     if (nt > n) nt = n;

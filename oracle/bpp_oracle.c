@@ -30,6 +30,18 @@ static int fail(int code, const char *msg) {
 
 int bpp_abi_version(void) { return BPP_ABI_VERSION; }
 const char *bpp_last_error(void) { return g_err; }
+/* the oracle has no launch shapes: the knobs are accepted and remembered, nothing depends on them */
+static bpp_knobs g_knobs = {0, 0, 1, 0, 0, {0, 0, 0}};
+int bpp_get_knobs(bpp_knobs *out) {
+    if (!out) return fail(BPP_E_BADARG, "bpp_get_knobs: NULL");
+    *out = g_knobs;
+    return 0;
+}
+int bpp_set_knobs(const bpp_knobs *k) {
+    if (!k) return fail(BPP_E_BADARG, "bpp_set_knobs: NULL");
+    g_knobs = *k;
+    return 0;
+}
 int bpp_limits(int32_t out[2]) {
     if (!out) return fail(BPP_E_BADARG, "bpp_limits: NULL");
     out[0] = 1 << 20;
@@ -441,8 +453,7 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
 int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
                  int32_t bound_lo, int32_t bound_hi, uint64_t seed0, int32_t threads) {
     (void)threads;
-    if (!pool || n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || bound_lo < 1 ||
-        bound_hi < 2 * bound_lo - 1)
+    if (!pool || !bpp_gen_cut2_args_ok(n, T, W, L, H, bound_lo, bound_hi))
         return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument");
     return bpp_gen_cut2_range(pool, lengths, 0, n, T, W, L, H, bound_lo, bound_hi, seed0)
                ? fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries") : 0;

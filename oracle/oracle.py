@@ -36,6 +36,17 @@ class StepOut(ctypes.Structure):
                                                                   ("sample_step", ctypes.c_uint64)]
 
 
+class Knobs(ctypes.Structure):
+    _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
+                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0):
+    """bpp_set_knobs of whatever library this front-end is bound to (meaningful for the emulated product)."""
+    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0)
+    _check(lib().bpp_set_knobs(ctypes.byref(k)))
+
+
 def build(force=False):
     """gcc the restatement into oracle/libbpp_oracle.so (no-op when up to date)."""
     if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)

@@ -30,3 +30,12 @@ def load_golden(name):
 ROLLOUT_CASES = ["rollout_cut2_10", "rollout_cut2_10_rot", "rollout_cut2_20", "rollout_rs_10",
                  "rollout_wide_8x12x9_rot", "rollout_short_5x4x6"]
 MASK_CASES = ["masks_10", "masks_20", "masks_7x13x8"]
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """The product kernels compiled for the host SIMT emulator (tests/emu/): numpy front-end with the
+    oracle's API, bound to the emulated libbpp_hip."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu_binding
+    return emu_binding.load()

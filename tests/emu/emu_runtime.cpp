@@ -1,0 +1,227 @@
+// TEST INFRASTRUCTURE ONLY -- cooperative-fiber SIMT emulator behind tests/emu/hip/hip_runtime.h.
+//
+// g++ compiles THIS file, which #includes the product kernel source verbatim, into tests/emu/libbpp_emu.so:
+// the same C ABI as libbpp_hip.so, but all pointers are host pointers and every launch runs here.
+//
+// Execution model (what the kernels are entitled to assume on gfx950, and nothing more):
+//   * a workgroup runs as blockDim.x fibers on one OS thread; a fiber runs until it reaches a rendezvous
+//     (ballot / shuffle / readfirstlane / wave barrier / __syncthreads) or returns;
+//   * when every fiber of the block is parked, each wave releases ONE group of lanes: those parked at the
+//     lowest source line among the exec-masked operations (ballot, shuffle) -- lanes still inside a loop body
+//     or a branch finish it before the lanes waiting behind it continue, the reconvergence a structured CFG
+//     gives on hardware -- and only when none is left, the lanes parked at a wave barrier / readfirstlane.
+//     CONVENTION this relies on (kept by the kernels): wave barriers and readfirstlane are called from
+//     wave-uniform control flow only, and a divergent loop that contains a ballot/shuffle is followed by one
+//     of them before control can reach the same source line again.  The group is the exec mask of the
+//     operation: ballot sees only those lanes, a shuffle from a lane outside it returns poison;
+//   * __syncthreads releases when every live fiber of the block has arrived;
+//   * lanes between two rendezvous run one after the other (ascending lane order, or descending with
+//     BPP_EMU_ORDER=reverse): LDS traffic between lanes that is not separated by a wave barrier shows up
+//     as a mismatch in at least one of the two orders instead of working by lock-step luck;
+//   * dynamic LDS is poisoned before every block.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+namespace emu {
+
+Idx g_blockIdx, g_blockDim, g_gridDim;
+
+struct Fiber {
+    void *sp;
+    char *stack;
+    unsigned tid;
+    int state;  // 0 runnable, 1 parked, 2 done
+    int kind, op, line, src;
+    uint64_t in, out;
+};
+
+static Fiber *g_cur = nullptr;
+static void *g_sched_sp = nullptr;
+static const std::function<void()> *g_body = nullptr;
+static std::vector<Fiber> g_fibers;
+static std::vector<char *> g_stacks;
+static constexpr size_t kStack = 256 * 1024;
+
+extern "C" void emu_switch(void **from_sp, void *to_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
+unsigned cur_tid() { return g_cur->tid; }
+
+static void fiber_main() {
+    (*g_body)();
+    g_cur->state = 2;
+    emu_switch(&g_cur->sp, g_sched_sp);
+    abort();  // a finished fiber is never resumed
+}
+
+static void prepare(Fiber &f) {
+    // initial frame: six callee-saved registers, then the entry address popped by `ret`; the entry must see
+    // rsp % 16 == 8 like after a call
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void **sp = (void **)(top - 8);   // slot that would hold a return address for fiber_main (never used)
+    *sp = nullptr;
+    *--sp = (void *)&fiber_main;      // `ret` target; after ret rsp = top - 8  (== 8 mod 16)
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;
+    f.sp = (void *)sp;
+    f.state = 0;
+}
+
+uint64_t rendezvous(int kind, int op, int line, uint64_t val, int src_lane) {
+    Fiber *f = g_cur;
+    f->kind = kind;
+    f->op = op;
+    f->line = line;
+    f->in = val;
+    f->src = src_lane;
+    f->state = 1;
+    emu_switch(&f->sp, g_sched_sp);
+    return f->out;
+}
+
+static void fatal(const char *msg) {
+    fprintf(stderr, "emu: %s\n", msg);
+    abort();
+}
+
+static void release_wave_group(Fiber *w, int nl, int line) {
+    uint64_t ballot = 0, first = 0;
+    bool have_first = false;
+    int op = -1;
+    for (int l = 0; l < nl; ++l) {
+        Fiber &f = w[l];
+        if (f.state != 1 || f.kind != K_WAVE || f.line != line) continue;
+        if (op < 0) op = f.op;
+        else if (op != f.op) fatal("different wave operations parked on one source line");
+        if (f.in & 1u) ballot |= 1ull << l;
+        if (!have_first) {
+            first = f.in;
+            have_first = true;
+        }
+    }
+    for (int l = 0; l < nl; ++l) {
+        Fiber &f = w[l];
+        if (f.state != 1 || f.kind != K_WAVE || f.line != line) continue;
+        switch (f.op) {
+            case OP_BALLOT: f.out = ballot; break;
+            case OP_FIRST: f.out = first; break;
+            case OP_SHFL: {
+                const int s = f.src;
+                const bool ok = s >= 0 && s < nl && w[s].state == 1 && w[s].kind == K_WAVE && w[s].line == line;
+                f.out = ok ? w[s].in : 0xBAD0BAD0BAD0BAD0ull;  // source lane not in the exec mask
+                break;
+            }
+            default: f.out = 0; break;
+        }
+    }
+    for (int l = 0; l < nl; ++l) {
+        Fiber &f = w[l];
+        if (f.state == 1 && f.kind == K_WAVE && f.line == line) f.state = 0;
+    }
+}
+
+}  // namespace emu
+
+// dynamic LDS of the running workgroup: the kernels' `extern __shared__ ... smem[]` declarations (block scope,
+// inside the anonymous namespace of the included source) bind to this definition
+namespace {
+alignas(16) unsigned char smem[160 * 1024];
+}
+
+namespace emu {
+
+void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()> &body) {
+    if (lds > sizeof(smem)) fatal("LDS request above 160 KiB");
+    if (block.x == 0 || block.x > 1024 || block.y != 1 || block.z != 1) fatal("unsupported block shape");
+    if (g_cur != nullptr) fatal("nested launch");
+    const char *ord = getenv("BPP_EMU_ORDER");
+    const bool reverse = ord && ord[0] == 'r';
+    const unsigned nt = block.x;
+    while (g_stacks.size() < nt) g_stacks.push_back((char *)malloc(kStack));
+    g_fibers.resize(nt);
+    g_blockDim = Idx{block.x, 1, 1};
+    g_gridDim = Idx{grid.x, grid.y, grid.z};
+    g_body = &body;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        g_blockIdx = Idx{b, 0, 0};
+        memset(smem, 0xCD, lds);
+        for (unsigned t = 0; t < nt; ++t) {
+            Fiber &f = g_fibers[t];
+            f.stack = g_stacks[t];
+            f.tid = t;
+            prepare(f);
+        }
+        for (;;) {
+            bool ran = false;
+            for (unsigned k = 0; k < nt; ++k) {
+                Fiber &f = g_fibers[reverse ? nt - 1 - k : k];
+                if (f.state != 0) continue;
+                g_cur = &f;
+                emu_switch(&g_sched_sp, f.sp);
+                g_cur = nullptr;
+                ran = true;
+            }
+            // everything is parked or done
+            unsigned done = 0, at_block = 0;
+            bool released = false;
+            for (unsigned w0 = 0; w0 < nt; w0 += 64) {
+                const int nl = (int)std::min(64u, nt - w0);
+                // exec-masked operations (ballot, shuffle) first, lowest source line first; wave barriers and
+                // readfirstlane are wave-uniform in this code base (convention, see header) and wait until no
+                // lane of the wave is still inside a divergent region
+                int best = -1, best_uniform = -1;
+                for (int l = 0; l < nl; ++l) {
+                    const Fiber &f = g_fibers[w0 + l];
+                    if (f.state == 2) ++done;
+                    else if (f.state == 1 && f.kind == K_BLOCK) ++at_block;
+                    else if (f.state == 1 && (f.op == OP_BALLOT || f.op == OP_SHFL)) {
+                        if (best < 0 || f.line < best) best = f.line;
+                    } else if (f.state == 1) {
+                        if (best_uniform < 0 || f.line < best_uniform) best_uniform = f.line;
+                    }
+                }
+                if (best < 0) best = best_uniform;
+                if (best >= 0) {
+                    release_wave_group(&g_fibers[w0], nl, best);
+                    released = true;
+                }
+            }
+            if (released) continue;
+            if (done == nt) break;
+            if (done + at_block == nt) {
+                for (unsigned t = 0; t < nt; ++t)
+                    if (g_fibers[t].state == 1) g_fibers[t].state = 0;
+                continue;
+            }
+            if (!ran) fatal("deadlock");
+        }
+    }
+    g_body = nullptr;
+}
+
+}  // namespace emu
+
+#include "../../online-3d-bpp-drl_amd/csrc/bpp_kernels.hip"

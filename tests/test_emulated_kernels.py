@@ -1,0 +1,149 @@
+"""Kernel LOGIC on the CPU: the product kernel source (csrc/bpp_kernels.hip, unmodified) compiled by g++
+against the cooperative-fiber SIMT emulator under tests/emu/ and compared bit for bit with the golden
+vectors recorded from the reference and with the oracle.  Same comparisons as tests/test_gpu_parity.py at
+sizes a host can step in seconds; both kernel paths, both lane execution orders (a cross-lane LDS dependence
+without a wave barrier differs between them), every tuning-knob shape.  This is a development aid and an
+early warning -- the parity claim itself is the `-m gpu` suite on the MI355X."""
+import numpy as np
+import pytest
+
+from conftest import MASK_CASES, ROLLOUT_CASES, load_golden
+from test_oracle_golden import check_masks, check_rollout
+
+
+@pytest.fixture(params=["fast-asc", "fast-desc", "generic-asc"])
+def variant(request, emu, monkeypatch):
+    path, order = request.param.split("-")
+    emu.set_knobs(force_generic=int(path == "generic"))
+    monkeypatch.setenv("BPP_EMU_ORDER", "reverse" if order == "desc" else "forward")
+    yield request.param
+    emu.set_knobs()
+
+
+@pytest.mark.parametrize("case", ROLLOUT_CASES)
+def test_emulated_rollout_matches_reference_golden(emu, variant, case):
+    check_rollout(lambda pool, size, rot, E, rule: emu.EmuEnv(pool, size, rot, E, mask_rule=rule), load_golden(case))
+
+
+@pytest.mark.parametrize("case", MASK_CASES)
+def test_emulated_masks_match_reference_golden(emu, variant, case):
+    check_masks(emu.mask_from_obs, emu.mask_from_hmap, load_golden(case))
+
+
+GEOMS = [((10, 10, 10), False, 150, 11), ((10, 10, 10), True, 90, 12), ((20, 20, 20), False, 21, 13),
+         ((7, 13, 8), True, 33, 14), ((5, 4, 6), False, 37, 15), ((32, 32, 40), True, 3, 16),
+         ((20, 20, 10), True, 13, 17), ((20, 20, 22), True, 9, 18), ((10, 10, 11), False, 20, 20),
+         ((2, 2, 5), True, 20, 21), ((1, 3, 4), False, 13, 22), ((1, 1, 3), True, 7, 24),
+         ((8, 128, 10), True, 5, 25), ((4, 255, 10), False, 5, 26), ((14, 72, 12), True, 3, 27), ((12, 81, 9), False, 3, 28)]
+
+
+@pytest.mark.parametrize("size,rot,E,seed", GEOMS)
+def test_emulated_vs_oracle_random_rollout(emu, oracle, variant, size, rot, E, seed):
+    """Seeded rollouts with some invalid actions, a mid-run reset, bin-sized items; bins not a multiple of the
+    per-wave group; elongated bins (L up to 255) that stress the candidate index decode."""
+    rng = np.random.RandomState(seed)
+    lo, hi = 1, max(2, min(size) // 2)
+    seqs = [[tuple(rng.randint(lo, hi + 1, size=3)) for _ in range(rng.randint(3, 40))] for _ in range(17)]
+    seqs[3][1] = (size[0], size[1], 1)
+    seqs[5][0] = (size[0], max(1, size[1] - 1), 2)
+    seqs[7][0] = (1, 1, 1)
+    seqs[8][0] = (min(2, size[0]), 1, 1)
+    from bpp_amd import sequences
+    pool = sequences.pad_pool(seqs, size)
+    steps = 24 if size[0] * size[1] <= 400 else 10
+    for rule in (0, 1):
+        env = emu.EmuEnv(pool, size, rot, E, env_id_base=5, env_id_total=E + 9, mask_rule=rule)
+        ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=5, env_id_total=E + 9, mask_rule=rule)
+        obs, mask = env.reset()
+        robs, rmask = ref.reset()
+        np.testing.assert_array_equal(obs, robs)
+        np.testing.assert_array_equal(mask, rmask)
+        M = env.M
+        for t in range(steps):
+            a = emu.sample_feasible(mask, seed, t, env_id_base=5)
+            np.testing.assert_array_equal(a, oracle.sample_feasible(rmask, seed, t, env_id_base=5))
+            bad = rng.rand(E) < 0.05
+            a[bad] = rng.randint(-2, M + 3, size=int(bad.sum()))
+            r, o = env.step(a), ref.step(a)
+            for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg="%s t=%d rule=%d" % (k, t, rule))
+            mask = rmask = o["mask"]
+            if t == steps // 2:
+                np.testing.assert_array_equal(env.reset()[0], ref.reset()[0])
+                mask = rmask = ref.out["mask"].copy()
+                np.testing.assert_array_equal(env.out["mask"], rmask)
+        np.testing.assert_array_equal(env.hmap, ref.hmap)
+        for f in ref.state.dtype.names:
+            if f != "pad":
+                np.testing.assert_array_equal(env.state[f], ref.state[f], err_msg=f)
+        np.testing.assert_array_equal(env.stats.sum(0)[2:], ref.stats.sum(0)[2:])
+        np.testing.assert_allclose(env.stats.sum(0)[:2], ref.stats.sum(0)[:2], rtol=1e-12)
+
+
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 99), ((10, 10, 10), True, 70), ((20, 20, 20), False, 11),
+                                         ((7, 13, 8), True, 19)])
+def test_emulated_native_driver_and_fused_draw(emu, oracle, variant, size, rot, E):
+    """bpp_rollout_uniform with the in-kernel draw of the next action == the oracle's driver."""
+    from bpp_amd import sequences
+    pool = sequences.cut2_pool(size, 16, seed=3, bound=(2, min(5, min(size) // 2)), native=False)
+    env = emu.EmuEnv(pool, size, rot, E, env_id_base=7, env_id_total=E + 7)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=7, env_id_total=E + 7)
+    env.reset(), ref.reset()
+    for step0, n in ((0, 9), (9, 14)):
+        r, ra = emu.rollout_uniform(env, 9, step0, n)
+        o, oa = oracle.rollout_uniform(ref, 9, step0, n)
+        np.testing.assert_array_equal(ra, oa)
+        for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=k)
+    np.testing.assert_array_equal(env.hmap, ref.hmap)
+
+
+@pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
+def test_emulated_tuning_knobs_do_not_change_results(emu, epw, wpb):
+    emu.set_knobs(bins_per_wave=epw, waves_per_group=wpb, xcd_remap=(epw + wpb) & 1)
+    try:
+        for case in ("rollout_cut2_10_rot", "rollout_wide_8x12x9_rot"):
+            check_rollout(lambda pool, size, rot, E, rule: emu.EmuEnv(pool, size, rot, E, mask_rule=rule), load_golden(case))
+    finally:
+        emu.set_knobs()
+
+
+def test_emulated_masks_property_random_geometries(emu, oracle, variant):
+    rng = np.random.RandomState(99)
+    for trial in range(40):
+        W, L, H = rng.randint(1, 14), rng.randint(1, 14), rng.randint(1, 15)
+        if trial % 8 == 0:
+            W, L = rng.randint(2, 5), rng.randint(65, 256)    # elongated: L > 64 (candidate index decode)
+            W = min(W, 1024 // L)
+        n = rng.randint(1, 12)
+        hm = rng.randint(0, H + 2, size=(n, W * L)).astype(np.int32)
+        hm[rng.rand(n) < 0.4] = rng.randint(0, H + 1)
+        items = np.stack([rng.randint(0, W + 2, n), rng.randint(0, L + 2, n), rng.randint(0, H + 1, n)], 1).astype(np.int32)
+        size = (W, L, H)
+        A = W * L
+        obs = np.concatenate([hm, np.repeat(items[:, 0:1], A, 1), np.repeat(items[:, 1:2], A, 1),
+                              np.repeat(items[:, 2:3], A, 1)], 1).astype(np.float32)
+        for rot in (False, True):
+            for rule in (0, 1):
+                want = oracle.mask_from_hmap(hm, items, size, rot, rule)
+                np.testing.assert_array_equal(emu.mask_from_hmap(hm, items, size, rot, rule), want,
+                                              err_msg="hmap %r rot=%d rule=%d" % (size, rot, rule))
+                np.testing.assert_array_equal(emu.mask_from_obs(obs, size, rot, rule), want,
+                                              err_msg="obs %r rot=%d rule=%d" % (size, rot, rule))
+
+
+def test_emulated_masked_act_and_stats(emu, oracle):
+    rng = np.random.RandomState(5)
+    for M in (100, 200, 400, 36, 512):
+        E = 37
+        logits = rng.randn(E, M).astype(np.float32) * 3
+        mask = (rng.rand(E, M) < 0.3).astype(np.float32)
+        mask[0] = 0
+        for det in (False, True):
+            a, lp = emu.masked_act(logits, mask, 3, 7, det, env_id_base=11)
+            oa, olp = oracle.masked_act(logits, mask, 3, 7, det, env_id_base=11)
+            np.testing.assert_array_equal(a, oa)
+            np.testing.assert_allclose(lp, olp, rtol=0, atol=5e-6)
+    done = (rng.rand(1000) < 0.2).astype(np.uint8)
+    ret, ratio, ln = rng.rand(1000), rng.rand(1000), rng.randint(1, 50, 1000).astype(np.int32)
+    np.testing.assert_allclose(emu.episode_stats(done, ret, ratio, ln), oracle.episode_stats(done, ret, ratio, ln), rtol=1e-12)

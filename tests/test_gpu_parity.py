@@ -21,14 +21,20 @@ def bpp():
 
 
 @pytest.fixture(params=["fast", "generic"])
-def kernel_path(request, monkeypatch):
+def kernel_path(request, bpp):
     """Every geometry with a compiled fast path (packed-histogram prefix image) is also run through
     the generic cell-scan kernel; geometries without one run the generic kernel twice (cheap)."""
-    if request.param == "generic":
-        monkeypatch.setenv("BPP_FORCE_GENERIC", "1")
-    else:
-        monkeypatch.delenv("BPP_FORCE_GENERIC", raising=False)
-    return request.param
+    old = bpp._lib.set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=int(request.param == "generic"))
+    yield request.param
+    bpp._lib.set_knobs(**old)
+
+
+@pytest.fixture
+def knobs(bpp):
+    """Set launch-shape knobs for one test (bpp_set_knobs), restored afterwards."""
+    saved = bpp._lib.get_knobs()
+    yield lambda **kw: bpp._lib.set_knobs(**kw)
+    bpp._lib.set_knobs(**saved)
 
 
 class GpuEnv(object):
@@ -433,12 +439,10 @@ def test_gpu_example_policy_in_the_loop_runs():
 
 
 @pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
-def test_gpu_tuning_knobs_do_not_change_results(bpp, monkeypatch, epw, wpb):
+def test_gpu_tuning_knobs_do_not_change_results(bpp, knobs, epw, wpb):
     """Every bins-per-wave / waves-per-workgroup setting (incl. workgroups above 64 KiB of LDS and a wave
     serving 64 bins) replays the reference's golden rollouts bit for bit, with and without XCD remapping."""
-    monkeypatch.setenv("BPP_EPW", str(epw))
-    monkeypatch.setenv("BPP_WPB", str(wpb))
-    monkeypatch.setenv("BPP_XCD", str((epw + wpb) & 1))
+    knobs(bins_per_wave=epw, waves_per_group=wpb, xcd_remap=(epw + wpb) & 1)
     for case in ("rollout_cut2_10_rot", "rollout_cut2_20", "rollout_wide_8x12x9_rot"):
         g = load_golden(case)
         size = tuple(int(v) for v in g["size"])

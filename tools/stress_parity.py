@@ -34,11 +34,9 @@ for trial in range(args.trials):
     if rng.rand() < 0.3:
         seqs[0][0] = size[:2] + (1,)
     pool = bpp_amd.sequences.pad_pool(seqs, size if rng.rand() < 0.7 else (1, 1, 1))
-    for k, v in (("BPP_EPW", rng.choice(["", "1", "2", "4", "8"])), ("BPP_WPB", rng.choice(["", "1", "2", "4", "8"])),
-                 ("BPP_FORCE_GENERIC", rng.choice(["", "", "1"]))):
-        os.environ.pop(k, None)
-        if v:
-            os.environ[k] = v
+    knobs = dict(bins_per_wave=int(rng.choice([0, 1, 2, 4, 8])), waves_per_group=int(rng.choice([0, 1, 2, 4, 8])),
+                 force_generic=int(rng.choice([0, 0, 1])), xcd_remap=int(rng.choice([0, 1])))
+    bpp_amd._lib.set_knobs(**knobs)
     base, total = int(rng.randint(0, 50)), None
     total = base + E + int(rng.randint(0, 9))
     rule = "space" if (rng.rand() < 0.3) else "utils"
@@ -55,12 +53,12 @@ for trial in range(args.trials):
     ref.reset()
     o, _ = orc.rollout_uniform(ref, trial, 5, n)
     for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
-        assert np.array_equal(getattr(r, k).cpu().numpy(), o[k]), (trial, size, rot, E, k, dict(os.environ))
+        assert np.array_equal(getattr(r, k).cpu().numpy(), o[k]), (trial, size, rot, E, k, knobs)
     assert np.array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
     assert np.array_equal(env.hmap.cpu().numpy(), ref.hmap)
     st = env.state_numpy()
     for f in st.dtype.names:
         if f != "pad":
             assert np.array_equal(st[f], ref.state[f]), (trial, f)
-    paths["generic" if (os.environ.get("BPP_FORCE_GENERIC") or (W * L) % 4 or H > 22) else "fast"] += 1
+    paths["generic" if (knobs["force_generic"] or (W * L) % 4 or H > 22) else "fast"] += 1
 print("stress parity ok:", args.trials, "trials,", paths)
