@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--pool-file", default=None,
                     help="npz with a uint8 [P][T][4] `pool` array instead of generated sequences, e.g. "
                          "tests/golden/cut2_dataset_10.npz = the reference's dataset/cut_2.pt (2100 sequences)")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: enough "
+                         "repetitions for >= 100 ms of timed work, at most 25, so that a small --steps is not a 1 ms sample)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -103,11 +106,41 @@ def cpu_baseline(pool, size, rotation, seconds):
         res = pw.map(_cpu_worker, jobs)
     rate = sum(bins * n / dt for n, dt in res)     # every worker measured over its own busy interval
     return {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "single_core_value": single,
+            "single_core_value": single, "reference_python_context": reference_python_context(),
             "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "
                       "%d processes x %d bins for %.1f s each (sum of per-process rates), and %d bins x %d lock-steps "
                       "in %.1f s on one core; same CUT-2 pool and uniform-feasible policy; os.cpu_count()=%s"
                       % (cores, bins, 0.5 * seconds, bins, n1, dt1, os.cpu_count())}
+
+
+def reference_python_context():
+    """The UNMODIFIED reference Python cannot run on the GPU box (/root/reference is not shipped there); its
+    host throughput was measured in the build container (oracle/time_reference.py) and is carried here as
+    labelled context next to the C port's number -- not measured in this run, not on this box."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_reference_python_cpu_here.json")))
+        d = dict(d)
+        d["note"] = ("measured in the build container (8 cores), not on this box and not in this run: the reference "
+                     "tree does not travel to the GPU box; profiles/r01_reference_python_cpu_here.json")
+        return d
+    except Exception:
+        return None
+
+
+def profile_evidence(key):
+    """Counter-derived facts about the step kernel for this workload from profiles/hbm_traffic.json (written by
+    tools/pmc_to_json.py from rocprofv3 PMC passes of the same bench command): HBM bytes per launch, VALU
+    utilisation.  None when no profile of this workload is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        v = d.get(key)
+        if isinstance(v, dict):
+            return v
+        if isinstance(v, (int, float)):
+            return {"traffic_bytes": v}
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -146,11 +179,16 @@ def main():
     dev_index = 0 if os.environ.get("BPP_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # BPP_BENCH_FORCE_PG=1: initialise the process group (and run the barrier / stats all-reduce through it) even
+    # with ONE rank, so that the RCCL branch can be exercised on a 1-GPU box; never set by the driver.
+    use_pg = world > 1 or bool(os.environ.get("BPP_BENCH_FORCE_PG"))
+    if use_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=pool, device=device,
                             env_id_base=rank * E, env_id_total=world * E)
@@ -164,7 +202,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -173,24 +211,37 @@ def main():
     env.rollout_uniform(seed=1, step0=0, nsteps=args.warmup, actions=actions)
     stats.collect(env).all_reduce()   # also loads the few torch kernels the collection uses
     stats.zero_()
-    fence()
-    t0 = time.perf_counter()
-    env.rollout_uniform(seed=1, step0=args.warmup, nsteps=args.steps, actions=actions)
-    stats.collect(env).all_reduce()   # the only collective of the path: 32 bytes, once per logging interval
-    fence()
-    dt = time.perf_counter() - t0
+    # timed region = EXACTLY K lock-steps between two fences; repeated `reps` times back to back and the
+    # MEDIAN repetition reported, so that a small K is not a single sub-millisecond sample
+    def timed_region(step0):
+        fence()
+        t0 = time.perf_counter()
+        env.rollout_uniform(seed=1, step0=step0, nsteps=args.steps, actions=actions)
+        stats.collect(env).all_reduce()   # the only collective of the path: 32 bytes, once per logging interval
+        fence()
+        return time.perf_counter() - t0
+
+    first = timed_region(args.warmup)
+    reps = args.reps if args.reps > 0 else max(1, min(25, int(0.1 / max(first, 1e-6)) + 1))
+    if world > 1:   # every rank must run the same number of repetitions
+        rt = torch.tensor([reps], dtype=torch.int64, device=device)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        reps = int(rt.item())
+    samples = [first] + [timed_region(args.warmup + (r + 1) * args.steps) for r in range(reps - 1)]
+    if world > 1:   # a repetition takes as long as its slowest rank
+        tm = torch.tensor(samples, dtype=torch.float64, device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        samples = tm.cpu().tolist()
+    dt = sorted(samples)[len(samples) // 2]
+    done_steps = args.warmup + reps * args.steps
     # same K lock-steps driven step by step from Python (what a Python RL loop pays per step)
     fence()
     t1 = time.perf_counter()
-    env.sample_feasible(seed=1, step=args.warmup + args.steps, out=actions)
+    env.sample_feasible(seed=1, step=done_steps, out=actions)
     for t in range(args.steps):
-        lockstep(args.warmup + args.steps + t)
+        lockstep(done_steps + t)
     fence()
     dt_py = time.perf_counter() - t1
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     summary = stats.summary()
 
     # dominant kernel (bpp_step) launch duration, HIP events on the launch stream, after the timed region
@@ -198,31 +249,33 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for t, (e0, e1) in enumerate(evs):
         e0.record()
-        lockstep(args.warmup + 2 * args.steps + t)
+        lockstep(done_steps + args.steps + t)
         e1.record()
     torch.cuda.synchronize(device)
     kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     if rank == 0:
-        try:
-            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-        except Exception:
-            metric = "env steps/sec (whole node), 10^3 bin, 65536 envs; bit-exact mask vs ref"
+        headline = size == (10, 10, 10) and not args.rotation and E == 65536
+        metric = "env steps/sec (whole node), %dx%dx%d bin%s, %d envs per GPU; bit-exact mask vs ref" % (
+            size + (" + rotation" if args.rotation else "", E))
+        if headline:    # BASELINE.json's metric string belongs to its own workload only
+            try:
+                metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+            except Exception:
+                pass
         b_alg = algorithmic_bytes_per_env_step(A, M)
         achieved = b_alg * E / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%dx%dx%d_rot%d_E%d" % (size + (int(args.rotation), E)))
-            except Exception:
-                traffic = None
+        ev = profile_evidence("%dx%dx%d_rot%d_E%d" % (size + (int(args.rotation), E)))
+        traffic = ev.get("traffic_bytes") if ev else None
+        moved = traffic / (kern_avg_ms * 1e-3) / 1e9 if traffic else None
         out = {
             "metric": metric,
             "value": world * E * args.steps / dt,
             "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "reps": reps, "rep_ms_per_step_min_median_max": [min(samples) / args.steps * 1e3, dt / args.steps * 1e3,
+                                                            max(samples) / args.steps * 1e3],
             "ms_per_step": dt / args.steps * 1e3,
             "python_loop_ms_per_step": dt_py / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -231,20 +284,27 @@ def main():
                                    % (size + (" + rotation" if args.rotation else "", E)),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
                        "pool_source": args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)",
-                       "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s)"
-                                   % (world, "RCCL" if backend == "nccl" else backend),
+                       "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s%s)"
+                                   % (world, "RCCL" if backend == "nccl" else backend,
+                                      "" if use_pg else ", no process group at 1 rank"),
                        "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
                        "mean_episode_length": round(summary["mean_length"], 2)},
+            # `achieved`/`frac`: ALGORITHMIC bytes (int32 heightmaps as in the reference's layout) per
+            # launch / launch duration.  `achieved_moved`/`frac_moved`: the bytes the kernel really moves (PMC
+            # counters; the state is kept as bytes, so fewer than the algorithmic ones) / the same duration -- the
+            # actual HBM bandwidth.  `limiter`: what the SQ counters say bounds the kernel today.
             "roofline": {"bound": "hbm", "kernel": "bpp_step (bpp_fast_kernel<W,L,K,ROT,kStep>)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+                         "achieved_moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+                         "limiter": (ev or {}).get("limiter"), "valu_utilisation": (ev or {}).get("valu_utilisation"),
                          "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
                          "launch_us_min": kern_ms[0] * 1e3},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

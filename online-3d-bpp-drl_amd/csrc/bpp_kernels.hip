@@ -1380,6 +1380,99 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
     }
 }
 
+// Same selection for rows the 16-lane kernel cannot take (M not a multiple of 4, or M > 512 such as the
+// 20x20 bin with rotation, M = 800): one wave per bin, entry k lives in lane k % 64, chunk k / 64; the CDF
+// walks the chunks in order with an inclusive wave scan per chunk.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+__global__ __launch_bounds__(256) void masked_act_kernel_generic(const float *logits, const float *mask, int64_t *action,
+                                                                 float *log_prob, int E, int M, int64_t env_id_base,
+                                                                 uint64_t seed, uint64_t step, int deterministic) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;  // whole waves leave; no block-level synchronisation below
+    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+    const int nchunk = (M + kWave - 1) / kWave;
+    float mx = -INFINITY;
+    for (int k = lane; k < M; k += kWave) mx = fmaxf(mx, x[k] - (1.0f - m[k]) * 14.0f);  // distributions.py:76-79
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
+    float part = 0.0f;
+    for (int k = lane; k < M; k += kWave) part += expf(x[k] - (1.0f - m[k]) * 14.0f - mx);
+    const float sum = wave_sum_f(part);
+    float lane_tot = 0.0f, best = -1.0f;
+    int best_i = 0;
+    for (int k = lane; k < M; k += kWave) {
+        const float pk = expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f;  // distributions.py:79-80
+        lane_tot += pk;
+        if (pk > best) {
+            best = pk;
+            best_i = k;
+        }
+    }
+    const float tot = wave_sum_f(lane_tot);
+    int a;
+    float pa;
+    if (deterministic) {  // dist.mode(): first index of the maximum
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float ob = __shfl_xor(best, d, kWave);
+            const int oi = __shfl_xor(best_i, d, kWave);
+            if (ob > best || (ob == best && oi < best_i)) {
+                best = ob;
+                best_i = oi;
+            }
+        }
+        a = best_i;
+        pa = best;
+    } else {
+        const float u = (float)(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)) >> 8) * (1.0f / 16777216.0f);
+        const float target = u * tot;
+        float base = 0.0f, pm = 0.0f;
+        int cand = 0x7fffffff;
+        for (int c = 0; c < nchunk; ++c) {  // wave-uniform trip count
+            const int k = c * kWave + lane;
+            const float pk = k < M ? expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f : 0.0f;
+            float incl = pk;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const float o = __shfl_up(incl, d, kWave);
+                if (lane >= d) incl += o;
+            }
+            if (cand == 0x7fffffff && k < M && base + incl > target) {
+                cand = k;
+                pm = pk;
+            }
+            base += __shfl(incl, kWave - 1, kWave);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int oc = __shfl_xor(cand, d, kWave);
+            const float op = __shfl_xor(pm, d, kWave);
+            if (oc < cand) {
+                cand = oc;
+                pm = op;
+            }
+        }
+        if (cand == 0x7fffffff) {  // rounding at u ~ 1: the last entry
+            cand = M - 1;
+            pm = expf(x[M - 1] - (1.0f - m[M - 1]) * 14.0f - mx) / sum + 1e-5f;
+        }
+        a = cand;
+        pa = pm;
+    }
+    if (lane == 0) {
+        action[e] = a;
+        if (log_prob) {
+            const float eps = 1.1920928955078125e-7f;
+            log_prob[e] = logf(fminf(fmaxf(pa / tot, eps), 1.0f - eps));
+        }
+    }
+}
+
 // Fallback for rows that are not a multiple of 4 floats or longer than 16 * 8 quads: one wave per bin.
 __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, int64_t *actions, int E, int M,
                                                              int64_t env_id_base, uint64_t seed, uint64_t step) {
@@ -1801,9 +1894,13 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
                    int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream) {
     if (!logits || !mask || !action) return fail(BPP_E_BADARG, "bpp_masked_act: NULL pointer");
     if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_act: non-positive size");
-    if (M % 4 != 0 || M > 16 * 8 * 4) return fail(BPP_E_TOOLARGE, "bpp_masked_act: M must be a multiple of 4 and <= 512");
-    if (!aligned16(logits) || !aligned16(mask)) return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (M % 4 != 0 || M > 16 * 8 * 4 || !aligned16(logits) || !aligned16(mask)) {  // wave-per-bin kernel: any M, any alignment
+        hipLaunchKernelGGL(masked_act_kernel_generic, dim3((E + 3) / 4), dim3(256), 0, st, logits, mask, action, log_prob, E, M,
+                           env_id_base, seed, step, deterministic);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+    }
     const int per = (M / 4 + 15) / 16;
     const int blocks = (E + 15) / 16;
 #define BPP_ACT(P) hipLaunchKernelGGL(masked_act_kernel<P>, dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step, deterministic)

@@ -105,11 +105,8 @@ def cut2_pool(container_size, n, seed=0, bound=(2, 5), T=None, native=True, thre
     """P = n CUT-2 sequences, sequence k drawn from random.Random(seed + k).  `native=True` runs the
     multithreaded C++ generator of the library (bpp_gen_cut2, bit-identical output: it re-implements CPython's
     MT19937 stream); `native=False` is the pure-Python restatement above."""
-    if native:
-        try:
-            return _cut2_pool_native(container_size, n, seed, bound, T, threads)
-        except (OSError, RuntimeError, AttributeError):
-            pass                      # library not built (e.g. docs tooling): same result from Python
+    if native:                        # no silent fallback: a missing/broken library raises
+        return _cut2_pool_native(container_size, n, seed, bound, T, threads)
     seqs = [cut2_sequence(container_size, bound, random.Random(seed + k)) for k in range(n)]
     return pad_pool(seqs, container_size, T)
 

@@ -42,9 +42,10 @@ class EpisodeStats(object):
                                                     res.ep_len.data_ptr(), res.done.numel(), self.acc.data_ptr(), s))
 
     def all_reduce(self, group=None):
-        """Sum the record over all ranks (no-op without an initialised process group)."""
+        """Sum the record over all ranks (no-op without an initialised process group; with one the collective
+        runs even for a single rank, so the RCCL path is the same code at every job size)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=group)
         return self
 

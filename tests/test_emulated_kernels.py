@@ -133,17 +133,30 @@ def test_emulated_masks_property_random_geometries(emu, oracle, variant):
 
 
 def test_emulated_masked_act_and_stats(emu, oracle):
+    """Both masked-act kernels (16 lanes per bin; wave per bin for M % 4 != 0 or M > 512, e.g. the 20x20 bin with
+    rotation) against the plain PyTorch float32 reference, with the tolerances of tests/test_masked_act.py."""
+    from test_masked_act import check
+    for E, M in ((37, 100), (21, 200), (9, 400), (11, 36), (7, 512), (9, 800), (13, 7), (6, 1023), (10, 130)):
+        check(lambda x, m, s, t, det: emu.masked_act(x, m, s, t, det), E, M, seed=E + M)
     rng = np.random.RandomState(5)
-    for M in (100, 200, 400, 36, 512):
-        E = 37
-        logits = rng.randn(E, M).astype(np.float32) * 3
-        mask = (rng.rand(E, M) < 0.3).astype(np.float32)
-        mask[0] = 0
-        for det in (False, True):
-            a, lp = emu.masked_act(logits, mask, 3, 7, det, env_id_base=11)
-            oa, olp = oracle.masked_act(logits, mask, 3, 7, det, env_id_base=11)
-            np.testing.assert_array_equal(a, oa)
-            np.testing.assert_allclose(lp, olp, rtol=0, atol=5e-6)
     done = (rng.rand(1000) < 0.2).astype(np.uint8)
     ret, ratio, ln = rng.rand(1000), rng.rand(1000), rng.randint(1, 50, 1000).astype(np.int32)
     np.testing.assert_allclose(emu.episode_stats(done, ret, ratio, ln), oracle.episode_stats(done, ret, ratio, ln), rtol=1e-12)
+
+
+@pytest.mark.parametrize("base,total,P", [(458752, 524288, 32), (458752, 524288, 31), (65536 * 3 + 5, 65536 * 4 + 77, 10),
+                                           (2 ** 31 - 700, 2 ** 31 + 12345, 17)])
+def test_emulated_shard_coordinates(emu, oracle, base, total, P):
+    """env_id_base / env_id_total of a multi-GPU rank (BASELINE config 5: rank 7 of 8), incl. ids beyond int32."""
+    from bpp_amd import sequences
+    size, E = (10, 10, 10), 70
+    pool = sequences.cut2_pool(size, P, seed=1, native=False)
+    env = emu.EmuEnv(pool, size, False, E, env_id_base=base, env_id_total=total)
+    ref = oracle.OracleEnv(pool, size, False, E, env_id_base=base, env_id_total=total)
+    env.reset(), ref.reset()
+    r, ra = emu.rollout_uniform(env, 3, 0, 40)
+    o, oa = oracle.rollout_uniform(ref, 3, 0, 40)
+    for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+        np.testing.assert_array_equal(r[k], o[k], err_msg=k)
+    for f in ("seq", "episode", "cursor", "item_cur", "item_next", "item_reset"):
+        np.testing.assert_array_equal(env.state[f], ref.state[f], err_msg=f)

@@ -479,3 +479,58 @@ def test_gpu_mask_entry_points_clamp_oversized_items(bpp, oracle):
     want = oracle.mask_from_hmap(hm, items, size, True, 0)
     assert want[0].min() == 1 and want[1].min() == 1 and want[2].sum() == 128
     np.testing.assert_array_equal(bpp.batched_mask_from_hmap(hm, items, size, True, "utils").cpu().numpy(), want)
+
+
+def _lockstep_all_bins(bpp, oracle, size, rot, E, base, total, P, steps=12, seed=17):
+    """HIP vs oracle on EVERY bin of a full-size shard: observation, mask, reward, done, counter, ratio,
+    Monitor sums every step; byte heightmaps and complete state records at the end.  Step `steps // 2` forces
+    failures on a third of the bins (corner placement), so auto-reset and pool-row advance happen mid-grid."""
+    pool = bpp.sequences.cut2_pool(size, P, seed=1)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, env_id_base=base, env_id_total=total)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=base, env_id_total=total)
+    obs = env.reset()
+    robs, rmask = ref.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), robs)
+    np.testing.assert_array_equal(env.location_masks.cpu().numpy(), rmask)
+    A = size[0] * size[1]
+    finished = 0
+    for t in range(steps):
+        a = env.sample_feasible(seed=seed, step=t)
+        if t == steps // 2:
+            a[::3] = A - 1
+        r = env.step_tensors(a)
+        o = ref.step(a.cpu().numpy(), copy=False)
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg="%s t=%d" % (k, t))
+        np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"], err_msg="reward t=%d" % t)
+        finished += int(o["done"].sum())
+    np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    st = env.state_numpy()
+    for f in st.dtype.names:
+        if f != "pad":
+            np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
+    got, want = env.episode_stats().cpu().numpy(), ref.stats.sum(0)
+    np.testing.assert_array_equal(got[2:], want[2:])
+    np.testing.assert_allclose(got[:2], want[:2], rtol=1e-11)
+    assert finished > E // 4
+
+
+@pytest.mark.parametrize("path,xcd", [("fast", 1), ("fast", 0), ("generic", 1)])
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 65536), ((10, 10, 10), True, 65536),
+                                         ((20, 20, 20), False, 32768)])
+def test_gpu_full_size_every_bin_matches_oracle(bpp, oracle, knobs, size, rot, E, path, xcd):
+    """BASELINE.json configs 2-4 at full size, ALL bins compared (not slices): the XCD block remap, tail
+    workgroups and middle-of-grid bins are covered on both kernel paths, remap on and off."""
+    knobs(force_generic=int(path == "generic"), xcd_remap=xcd, bins_per_wave=0, waves_per_group=0)
+    _lockstep_all_bins(bpp, oracle, size, rot, E, 0, E, 64 if size[0] > 10 else 512)
+
+
+@pytest.mark.parametrize("base,total,P", [(458752, 524288, 8192),      # BASELINE config 5, rank 7 of 8
+                                           (458752, 524288, 8191),      # prime pool: base_mod and seq_stride both wrap
+                                           (65536 * 3 + 5, 65536 * 4 + 77, 1000),
+                                           (2 ** 31 - 70000, 2 ** 31 + 12345, 4099)])   # ids beyond int32
+def test_gpu_shard_coordinates_of_multi_gpu_jobs(bpp, oracle, kernel_path, base, total, P):
+    """A rank of a multi-GPU job is a shard with env_id_base > 0: every bin of a full 65 536-bin shard at the
+    coordinates of BASELINE config 5's last rank (and at bases where base mod P / total mod P wrap) equals
+    the oracle stepping the same global ids."""
+    _lockstep_all_bins(bpp, oracle, (10, 10, 10), False, 65536, base, total, P, steps=10)

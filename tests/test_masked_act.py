@@ -74,7 +74,7 @@ def test_oracle_masked_act_sampling_frequencies(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("E,M", [(4099, 100), (1000, 200), (333, 400), (40, 8), (70, 512)])
+@pytest.mark.parametrize("E,M", [(4099, 100), (1000, 200), (333, 400), (40, 8), (70, 512), (129, 800), (33, 7), (50, 1023)])
 def test_gpu_masked_act_matches_torch_reference_and_oracle(oracle, E, M):
     import bpp_amd
 

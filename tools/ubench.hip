@@ -1,0 +1,258 @@
+// tools/ubench.hip -- instruction-cost micro-benchmarks for gfx950, used to price the step kernel's phases
+// (DESIGN.md section 3.1).  Not part of the product.  Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip
+//
+// Every test launches 256 CUs x `wps` waves per SIMD (256-thread workgroups = one wave per SIMD), each wave
+// issuing ITER x 64 copies of one instruction on 8 independent register chains; reported: ns per wave-instruction
+// per SIMD (time x / (wps x ITER x 64)) and the same relative to v_add_u32.  Also: calibration kernels for the
+// rocprofv3 FETCH_SIZE / WRITE_SIZE counters in the step kernel's own access widths (MI355X_MICROARCH.md, HBM).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+constexpr int ITER = 2000;
+
+#define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+#define REP64(S) REP8(S) REP8(S) REP8(S) REP8(S) REP8(S) REP8(S) REP8(S) REP8(S)
+
+// 32-bit VALU op with two sources: v[k] = op(v[k], c)
+#define DEF_VOP2(NAME, ASM)                                                          \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, uint32_t c0) {    \
+        uint32_t v[8];                                                               \
+        for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 8 + k + c0;                 \
+        uint32_t c = c0 | 3u;                                                        \
+        for (int it = 0; it < ITER; ++it) {                                          \
+            REP64(NAME##_STEP)                                                       \
+        }                                                                            \
+        uint32_t s = 0;                                                              \
+        for (int k = 0; k < 8; ++k) s ^= v[k];                                       \
+        if (s == 0x12345u) out[threadIdx.x] = s;                                     \
+    }
+
+#define add_u32_STEP(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(add_u32, "")
+#define mul_lo_STEP(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(mul_lo, "")
+#define mul_hi_STEP(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(mul_hi, "")
+#define mul_u24_STEP(k) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(mul_u24, "")
+#define mad_u24_STEP(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(mad_u24, "")
+#define lshl_add_STEP(k) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(lshl_add, "")
+#define add3_STEP(k) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(add3, "")
+#define cndmask_STEP(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(c) : );
+DEF_VOP2(cndmask, "")
+#define cmp_STEP(k) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(v[k]), "v"(c) : "vcc");
+DEF_VOP2(cmp, "")
+#define cvt_ubyte_STEP(k) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(v[k]));
+DEF_VOP2(cvt_ubyte, "")
+#define ffbh_STEP(k) asm volatile("v_ffbh_u32 %0, %0" : "+v"(v[k]));
+DEF_VOP2(ffbh, "")
+#define bfe_STEP(k) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(v[k]));
+DEF_VOP2(bfe, "")
+#define perm_STEP(k) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(perm, "")
+#define mov_dpp_STEP(k) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+DEF_VOP2(mov_dpp, "")
+#define add_dpp_STEP(k) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[k]));
+DEF_VOP2(add_dpp, "")
+#define readlane_STEP(k) asm volatile("v_readlane_b32 s20, %0, 3\n v_add_u32 %0, s20, %0" : "+v"(v[k]) : : "s20");
+DEF_VOP2(readlane, "")
+#define fma_f32_STEP(k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(fma_f32, "")
+#define pk_add_u16_STEP(k) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(pk_add_u16, "")
+#define sad_u8_STEP(k) asm volatile("v_sad_u8 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+DEF_VOP2(sad_u8, "")
+#define salu_STEP(k) asm volatile("s_add_u32 s20, s20, s21\n s_lshl_b32 s22, s22, 1" : : : "s20", "s21", "s22", "scc");
+DEF_VOP2(salu, "")
+
+// 64-bit ops on register pairs
+#define DEF_V64(NAME)                                                                \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, uint32_t c0) {    \
+        uint64_t v[8];                                                               \
+        for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 8 + k + c0;                 \
+        uint64_t c = ((uint64_t)c0 << 32) | 3u;                                      \
+        uint32_t sh = (c0 & 3u) + 1u;                                                \
+        for (int it = 0; it < ITER; ++it) {                                          \
+            REP64(NAME##_STEP)                                                       \
+        }                                                                            \
+        uint64_t s = 0;                                                              \
+        for (int k = 0; k < 8; ++k) s ^= v[k];                                       \
+        if (s == 0x12345u) out[threadIdx.x] = (uint32_t)s + sh;                      \
+    }
+#define lshl_add_u64_STEP(k) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(v[k]) : "v"(c));
+DEF_V64(lshl_add_u64)
+#define lshlrev_b64_STEP(k) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(v[k]) : "v"(sh));
+DEF_V64(lshlrev_b64)
+#define lshrrev_b64_STEP(k) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(v[k]) : "v"(sh));
+DEF_V64(lshrrev_b64)
+#define add_f64_STEP(k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_V64(add_f64)
+#define addc_pair_STEP(k) \
+    asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(*(uint32_t *)&v[k]) : "v"((uint32_t)c) : "vcc");
+DEF_V64(addc_pair)
+
+// LDS ops: address pattern = lane-linear (conflict-free) unless stated
+#define DEF_LDS(NAME, SETUP)                                                          \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, uint32_t c0) {     \
+        __shared__ uint64_t lds[4096];                                                \
+        for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i + c0;                \
+        __syncthreads();                                                              \
+        const uint32_t lane = threadIdx.x & 63u;                                      \
+        uint32_t addr = SETUP;                                                        \
+        uint64_t v[8];                                                                \
+        for (int k = 0; k < 8; ++k) v[k] = k;                                         \
+        for (int it = 0; it < ITER / 4; ++it) {                                       \
+            REP64(NAME##_STEP)                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)");                                     \
+        }                                                                             \
+        uint64_t s = 0;                                                               \
+        for (int k = 0; k < 8; ++k) s ^= v[k];                                        \
+        if (s == 0x12345u) out[threadIdx.x] = (uint32_t)s;                            \
+    }
+#define ds_read_b64_STEP(k) asm volatile("ds_read_b64 %0, %1 offset:" #k "*512" : "=v"(v[k]) : "v"(addr));
+DEF_LDS(ds_read_b64, (threadIdx.x >> 6) * 8192 + lane * 8)
+#define ds_read_b32_STEP(k) asm volatile("ds_read_b32 %0, %1 offset:" #k "*256" : "=v"(*(uint32_t *)&v[k]) : "v"(addr));
+DEF_LDS(ds_read_b32, (threadIdx.x >> 6) * 8192 + lane * 4)
+#define ds_read_u8_STEP(k) asm volatile("ds_read_u8 %0, %1 offset:" #k "*64" : "=v"(*(uint32_t *)&v[k]) : "v"(addr));
+DEF_LDS(ds_read_u8, (threadIdx.x >> 6) * 8192 + lane)
+#define ds_read_b64_s88_STEP(k) asm volatile("ds_read_b64 %0, %1 offset:" #k "*8" : "=v"(v[k]) : "v"(addr));
+DEF_LDS(ds_read_b64_s88, (threadIdx.x >> 6) * 8192 + (lane / 8) * 88 + (lane % 8) * 8)  // 11-entry row pitch like the 10x10 prefix image
+#define ds_write_b8_STEP(k) asm volatile("ds_write_b8 %1, %0 offset:" #k "*64" : : "v"(*(uint32_t *)&v[k]), "v"(addr));
+DEF_LDS(ds_write_b8, (threadIdx.x >> 6) * 8192 + lane)
+#define ds_write_b64_STEP(k) asm volatile("ds_write_b64 %1, %0 offset:" #k "*512" : : "v"(v[k]), "v"(addr));
+DEF_LDS(ds_write_b64, (threadIdx.x >> 6) * 8192 + lane * 8)
+#define ds_bpermute_STEP(k) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(*(uint32_t *)&v[k]) : "v"(addr));
+DEF_LDS(ds_bpermute, ((lane + 1) & 63u) * 4)
+
+// ---- counter calibration: known byte counts in the step kernel's access widths -------------------
+__global__ __launch_bounds__(256) void k_read4(const uint32_t *in, uint32_t *out, size_t n) {  // 4 B per lane loads
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) s ^= in[i];
+    if (s == 0x12345u) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_read16(const uint4 *in, uint32_t *out, size_t n) {  // 16 B per lane loads
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = in[i];
+        s ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (s == 0x12345u) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_write16(uint4 *out, size_t n, uint32_t c) {  // 16 B per lane stores
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = make_uint4(c, c + 1, c + 2, (uint32_t)i);
+}
+__global__ __launch_bounds__(256) void k_write4(uint32_t *out, size_t n, uint32_t c) {  // 4 B per lane stores
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c + (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *in, uint4 *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+template <typename K>
+static double time_kernel(K kern, int wps, uint32_t *dout, int reps = 3) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    double best = 1e30;
+    for (int r = 0; r < reps + 1; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(256 * wps), dim3(256), 0, 0, dout, 1u);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv) {
+    const bool calib = argc > 1 && !strcmp(argv[1], "calib");
+    uint32_t *dout;
+    CHECK(hipMalloc(&dout, 1 << 20));
+    if (calib) {
+        // run under: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE) --kernel-trace -- tools/ubench calib
+        const size_t bytes = (size_t)1 << 30;  // 1 GiB: far beyond the 256 MiB Infinity Cache
+        uint4 *a, *b;
+        CHECK(hipMalloc(&a, bytes));
+        CHECK(hipMalloc(&b, bytes));
+        CHECK(hipMemset(a, 1, bytes));
+        CHECK(hipMemset(b, 2, bytes));
+        CHECK(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        auto run = [&](const char *name, auto launch) {
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                CHECK(hipEventRecord(e0));
+                launch();
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            printf("{\"calib\": \"%s\", \"bytes\": %zu, \"ms\": %.4f, \"GBps\": %.1f}\n", name, bytes, best, bytes / best / 1e6);
+        };
+        const int grid = 256 * 32;
+        run("read4", [&] { hipLaunchKernelGGL(k_read4, dim3(grid), dim3(256), 0, 0, (const uint32_t *)a, dout, bytes / 4); });
+        run("read16", [&] { hipLaunchKernelGGL(k_read16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, dout, bytes / 16); });
+        run("write4", [&] { hipLaunchKernelGGL(k_write4, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
+        run("write16", [&] { hipLaunchKernelGGL(k_write16, dim3(grid), dim3(256), 0, 0, b, bytes / 16, 7u); });
+        run("copy16_half", [&] { hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, b, bytes / 32); });
+        return 0;
+    }
+    struct T {
+        const char *name;
+        void (*k)(uint32_t *, uint32_t);
+        int div;  // ITER divisor (LDS tests run ITER/4)
+        int per;  // instructions per STEP
+    };
+    const T tests[] = {
+        {"v_add_u32", k_add_u32, 1, 1}, {"v_mul_lo_u32", k_mul_lo, 1, 1}, {"v_mul_hi_u32", k_mul_hi, 1, 1},
+        {"v_mul_u32_u24", k_mul_u24, 1, 1}, {"v_mad_u32_u24", k_mad_u24, 1, 1}, {"v_lshl_add_u32", k_lshl_add, 1, 1},
+        {"v_add3_u32", k_add3, 1, 1}, {"v_cndmask_b32", k_cndmask, 1, 1}, {"v_cmp_lt_u32", k_cmp, 1, 1},
+        {"v_cvt_f32_ubyte1", k_cvt_ubyte, 1, 1}, {"v_ffbh_u32", k_ffbh, 1, 1}, {"v_bfe_u32", k_bfe, 1, 1},
+        {"v_perm_b32", k_perm, 1, 1}, {"v_mov_b32_dpp", k_mov_dpp, 1, 1}, {"v_add_u32_dpp", k_add_dpp, 1, 1},
+        {"v_readlane+v_add", k_readlane, 1, 2}, {"v_fma_f32", k_fma_f32, 1, 1}, {"v_pk_add_u16", k_pk_add_u16, 1, 1},
+        {"v_sad_u8", k_sad_u8, 1, 1}, {"s_add+s_lshl", k_salu, 1, 2},
+        {"v_lshl_add_u64", k_lshl_add_u64, 1, 1}, {"v_lshlrev_b64", k_lshlrev_b64, 1, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1, 1},
+        {"v_add_f64", k_add_f64, 1, 1}, {"v_add_co+v_addc", k_addc_pair, 1, 2},
+        {"ds_read_b64", k_ds_read_b64, 4, 1}, {"ds_read_b32", k_ds_read_b32, 4, 1}, {"ds_read_u8", k_ds_read_u8, 4, 1},
+        {"ds_read_b64 pitch88", k_ds_read_b64_s88, 4, 1}, {"ds_write_b8", k_ds_write_b8, 4, 1},
+        {"ds_write_b64", k_ds_write_b64, 4, 1}, {"ds_bpermute_b32", k_ds_bpermute, 4, 1},
+    };
+    double base = 0;
+    for (int wps : {8, 1}) {
+        for (const T &t : tests) {
+            const double ms = time_kernel(t.k, wps, dout);
+            const double n = (double)wps * (ITER / t.div) * 64.0 * t.per;  // wave-instructions per SIMD
+            const double ns = ms * 1e6 / n;
+            if (!strcmp(t.name, "v_add_u32")) base = ns;
+            printf("{\"test\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"ns_per_wave_instr\": %.4f, \"rel_v_add_u32\": %.3f}\n",
+                   t.name, wps, ms, ns, ns / base);
+        }
+    }
+    return 0;
+}
