@@ -89,7 +89,9 @@ def test_gpu_masked_act_matches_torch_reference_and_oracle(oracle, E, M):
         ag, lg = gpu(x, m, 5, 9, det)
         ao, lo = oracle.masked_act(x, m, 5, 9, det)
         assert (ag != ao).mean() < 0.01
-        np.testing.assert_allclose(lg[ag == ao], lo[ag == ao], rtol=0, atol=5e-6)
+        # the oracle sums sequentially in float32: its own error grows with M (the torch reference above is the
+        # authority for this kernel); 5e-6 up to 512 entries, 2.5e-8 per entry beyond
+        np.testing.assert_allclose(lg[ag == ao], lo[ag == ao], rtol=0, atol=max(5e-6, 2.5e-8 * M))
 
 
 def test_oracle_masked_act_against_the_reference_policy_head(oracle):

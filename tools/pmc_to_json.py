@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 PMC summaries (tools/profile_pmc.sh -> summary.txt) into profiles/hbm_traffic.json, the file
+bench.py reads `roofline.traffic` / `frac_moved` / `limiter` from.
+
+    python tools/pmc_to_json.py <key>=<summary.txt> [...]     e.g. 10x10x10_rot0_E65536=profiles/r02a_pmc_summary_10.txt
+
+Counter handling (MI355X_MICROARCH.md "HBM", calibrated on this box with tools/ubench calib, profiles/r02a_counter_calibration.txt):
+  * FETCH_SIZE and WRITE_SIZE are in KiB and come from separate passes;
+  * FETCH_SIZE reports exactly HALF of the bytes read, for 4-byte-per-lane and 16-byte-per-lane loads alike
+    (1 GiB read -> 524 298 KiB) -> doubled;
+  * WRITE_SIZE is exact for 4- and 16-byte-per-lane stores (1 GiB written -> 1 048 576 KiB) -> taken as is.
+VALU utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over all SIMDs) * 4 / (1024 SIMDs * kernel cycles),
+kernel cycles = SQ_BUSY_CYCLES / 32 shader engines.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(path):
+    d = {}
+    for line in open(path):
+        p = line.split()
+        if len(p) >= 4 and p[0] == "step":
+            d[p[1]] = float(p[3])
+    return d
+
+
+def main():
+    out_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        out = json.load(open(out_path))
+    except Exception:
+        out = {}
+    out["_comment"] = ("per bpp_step launch, from rocprofv3 PMC passes (tools/profile_pmc.sh, folded by tools/pmc_to_json.py): "
+                       "traffic_bytes = WRITE_SIZE KiB * 1024 + 2 * FETCH_SIZE KiB * 1024 (FETCH_SIZE reports half of the bytes "
+                       "read on gfx950, WRITE_SIZE is exact; calibrated with tools/ubench calib); valu_utilisation = "
+                       "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32)")
+    for arg in sys.argv[1:]:
+        key, path = arg.split("=", 1)
+        c = parse(path)
+        cyc = c["SQ_BUSY_CYCLES"] / 32.0
+        util = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        out[key] = {
+            "traffic_bytes": int(c["WRITE_SIZE"] * 1024 + 2 * c["FETCH_SIZE"] * 1024),
+            "write_bytes": int(c["WRITE_SIZE"] * 1024), "fetch_bytes_corrected": int(2 * c["FETCH_SIZE"] * 1024),
+            "valu_instructions": int(c["SQ_INSTS_VALU"]), "salu_instructions": int(c["SQ_INSTS_SALU"]),
+            "lds_instructions": int(c["SQ_INSTS_LDS"]), "waves": int(c["SQ_WAVES"]),
+            "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0),
+            "valu_utilisation": round(util, 3),
+            "limiter": ("valu issue (VALU pipes busy %.0f %% of the kernel)" % (100 * util)) if util > 0.6 else
+                       "memory / latency (VALU pipes busy %.0f %% of the kernel)" % (100 * util),
+            "source": os.path.relpath(os.path.abspath(path), ROOT),
+        }
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
