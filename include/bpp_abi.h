@@ -119,10 +119,20 @@ typedef struct bpp_knobs {
     int32_t xcd_remap;        /* 1 = give every XCD one contiguous eighth of the bins (default), 0 = off        */
     int32_t force_generic;    /* 1 = route every geometry through the generic cell-scan kernel                  */
     int32_t ablate;           /* profiling builds only (-DBPP_ENABLE_ABLATION): phase bit mask, else ignored    */
-    int32_t reserved[3];
+    int32_t legacy_fast;      /* 1 = run the runtime-geometry prefix-image kernel (bpp_fast_kernel) also for the
+                                 10x10 / 20x20 bins that have a compiled tile kernel (bpp_tile_kernel)          */
+    int32_t reserved[2];
 } bpp_knobs;
 int bpp_get_knobs(bpp_knobs *out);
 int bpp_set_knobs(const bpp_knobs *k);
+
+/* Which kernel and launch shape bpp_step / bpp_reset / bpp_mask_* use for a geometry under the current knobs
+ * (documentation and tests): out = {kernel, histogram words K, bins per wave, waves per workgroup, workgroups,
+ * LDS bytes per workgroup}. */
+#define BPP_KERNEL_CELLSCAN  0 /* bpp_kernel: any W*L <= 1024, per-candidate window scan                  */
+#define BPP_KERNEL_PREFIX_RT 1 /* bpp_fast_kernel: prefix image, runtime geometry (W*L % 4 == 0, H <= 22) */
+#define BPP_KERNEL_TILE      2 /* bpp_tile_kernel: prefix image, compile-time 10x10 / 20x20 geometry      */
+int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation, int32_t out[6]);
 
 int bpp_abi_version(void);
 const char *bpp_last_error(void);

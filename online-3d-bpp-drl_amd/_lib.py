@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "bpp_kernels.hip")
 LIB = os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
+DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
 ABI_VERSION = 5
 RULE_UTILS, RULE_SPACE = 0, 1
@@ -20,7 +21,7 @@ STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2",
-           "bpp_get_knobs", "bpp_set_knobs"]
+           "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info"]
 
 
 class Batch(ctypes.Structure):
@@ -42,7 +43,8 @@ class StepOut(ctypes.Structure):
 class Knobs(ctypes.Structure):
     """struct bpp_knobs"""
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
-                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
 
 def hipcc():
@@ -55,8 +57,7 @@ def hipcc():
 def build(force=False, verbose=False):
     """Compile csrc/bpp_kernels.hip for gfx950 into csrc/libbpp_hip.so (in-tree; no-op when fresh)."""
     def fresh():
-        return (os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC)
-                and os.path.getmtime(LIB) >= os.path.getmtime(HDR))
+        return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
     if not force and fresh():
         return LIB
@@ -103,6 +104,7 @@ def lib():
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_launch_info.argtypes = [ctypes.c_int32] * 5 + [ctypes.POINTER(ctypes.c_int32)]
         L.bpp_get_knobs.argtypes = [ctypes.POINTER(Knobs)]
         L.bpp_set_knobs.argtypes = [ctypes.POINTER(Knobs)]
         if L.bpp_abi_version() != ABI_VERSION:
@@ -120,7 +122,7 @@ def get_knobs():
     """Current launch-shape knobs as a dict (include/bpp_abi.h: bpp_knobs)."""
     k = Knobs()
     check(lib().bpp_get_knobs(ctypes.byref(k)))
-    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate")}
+    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate", "legacy_fast")}
 
 
 def set_knobs(**kw):
@@ -132,9 +134,22 @@ def set_knobs(**kw):
         if name not in new:
             raise TypeError("unknown knob %r" % (name,))
         new[name] = int(v)
-    k = Knobs(new["bins_per_wave"], new["waves_per_group"], new["xcd_remap"], new["force_generic"], new["ablate"])
+    k = Knobs(new["bins_per_wave"], new["waves_per_group"], new["xcd_remap"], new["force_generic"], new["ablate"],
+              new["legacy_fast"])
     check(lib().bpp_set_knobs(ctypes.byref(k)))
     return old
+
+
+KERNEL_NAMES = {0: "bpp_kernel (cell scan)", 1: "bpp_fast_kernel (prefix image, runtime geometry)",
+                2: "bpp_tile_kernel (prefix image, compile-time geometry)"}
+
+
+def launch_info(E, size, rotation=False):
+    """Kernel and launch shape used for a geometry under the current knobs (bpp_launch_info)."""
+    out = (ctypes.c_int32 * 6)()
+    check(lib().bpp_launch_info(int(E), int(size[0]), int(size[1]), int(size[2]), int(bool(rotation)), out))
+    return {"kernel": int(out[0]), "kernel_name": KERNEL_NAMES.get(int(out[0]), "?"), "K": int(out[1]), "bins_per_wave": int(out[2]),
+            "waves_per_group": int(out[3]), "workgroups": int(out[4]), "lds_bytes": int(out[5])}
 
 
 def limits():

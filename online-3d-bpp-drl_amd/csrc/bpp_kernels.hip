@@ -1190,6 +1190,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
 }
 
+#include "bpp_tile_kernel.inl"
+
 // Sub-groups of 16 lanes per bin (4 bins per wave): each lane owns `per` consecutive float4 quads of
 // the bin's mask row (16-byte loads), an inclusive scan inside the 16-lane row locates the pick-th set
 // entry in index order.  pick = (hash >> 32) * count >> 32.
@@ -1565,18 +1567,21 @@ int check_geometry(int E, int W, int L, int H, int rotation, int rule) {
 struct Launch {
     Params p;
     bool vec;
-    int fast;  // index into the fast-path geometry table, -1 = generic kernel
+    int fast;  // kRuntimeGeo + K - 1: prefix-image kernel with runtime geometry, -1 = generic kernel
+    int tile;  // index into kTileGeo (compile-time geometry, default launch shape), -1 = not the tile kernel
     int wpb;   // waves per workgroup (waves are independent; this only sets the LDS/dispatch granule)
     int blocks;
     size_t lds;
 };
 
-// Geometries with a compiled fast path: (W, L, K) with K 64-bit histogram words, H + 2 <= 12 * K.
-struct FastGeo {
-    int W, L, K;
+// Geometries with a compiled tile kernel: (W, L, K, EPW) with K 64-bit histogram words, H + 2 <= 12 * K, EPW bins
+// per wave.  Any other bin with W*L % 4 == 0 and H <= 22 -- and these, when the launch-shape knobs are set --
+// runs bpp_fast_kernel with runtime geometry.
+struct TileGeoEntry {
+    int W, L, K, epw;
 };
-constexpr FastGeo kFastGeo[] = {{10, 10, 1}, {20, 20, 1}, {20, 20, 2}, {10, 10, 2}};
-constexpr int kNumFastGeo = sizeof(kFastGeo) / sizeof(kFastGeo[0]);
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4}, {20, 20, 1, 1}, {20, 20, 2, 1}, {10, 10, 2, 4}};
+constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 
 // Tuning knobs (include/bpp_abi.h: bpp_knobs).  Initialised ONCE per process from the environment
@@ -1599,6 +1604,7 @@ bpp_knobs current_knobs() {
         g_knobs.xcd_remap = env_int("BPP_XCD", 1);
         g_knobs.force_generic = env_int("BPP_FORCE_GENERIC", 0);
         g_knobs.ablate = env_int("BPP_ABLATE", 0);
+        g_knobs.legacy_fast = env_int("BPP_LEGACY_FAST", 0);
         g_knobs_init = true;
     }
     return g_knobs;
@@ -1623,11 +1629,12 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     else
         while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16)) > 32 * 1024) epw >>= 1;
     l.fast = -1;
+    l.tile = -1;
     const bool gen = kn.force_generic != 0;
-    if (!gen)
-        for (int g = 0; g < kNumFastGeo; ++g)
-            if (kFastGeo[g].W == W && kFastGeo[g].L == L && H + 2 <= kLevelsPerWord * kFastGeo[g].K) {
-                l.fast = g;
+    if (!gen && !kn.legacy_fast && kn.bins_per_wave <= 0 && kn.waves_per_group <= 0)
+        for (int g = 0; g < kNumTileGeo; ++g)
+            if (kTileGeo[g].W == W && kTileGeo[g].L == L && H + 2 <= kLevelsPerWord * kTileGeo[g].K) {
+                l.tile = g;
                 break;
             }
     // any other bin whose area is a multiple of 4 and whose heights fit two histogram words runs the same
@@ -1637,7 +1644,7 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
         rt_k = H + 2 <= kLevelsPerWord ? 1 : 2;
         l.fast = kRuntimeGeo + rt_k - 1;
     }
-    const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * (rt_k ? rt_k : kFastGeo[l.fast].K) : 0;
+    const int pn_bytes = l.fast >= 0 ? (W + 1) * (L + 1) * 8 * rt_k : 0;
     if (l.fast >= 0 && kn.bins_per_wave <= 0) {
         // prefix image dominates LDS: keep a 4-wave block under 24 KiB (>= 6 blocks = 24 waves per CU).
         // Measured on MI355X: 10x10: EPW=4 39 us vs 43 us at EPW=8 and 50 us at EPW=2; 10x10 + rotation
@@ -1674,6 +1681,13 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     if (l.fast >= 0 && l.wpb * epw > kWave) l.wpb = kWave / epw;  // wave 0 carries one bin per lane
     l.blocks = (waves + l.wpb - 1) / l.wpb;
     l.lds = (size_t)l.wpb * p.lds_per_wave;
+    if (l.tile >= 0) {   // the tile kernel's launch shape is part of its type; only the grid depends on E
+        const int nb = kTileWaves * kTileGeo[l.tile].epw;
+        p.epw = kTileGeo[l.tile].epw;
+        l.wpb = kTileWaves;
+        l.blocks = (E + nb - 1) / nb;
+        l.lds = 0;       // filled in by launch_tile from TileGeo<...>::LDS_BLOCK
+    }
     return l;
 }
 
@@ -1701,17 +1715,27 @@ void launch_fast(const Launch &l, hipStream_t s) {
         launch_fast_rot<W, L, K, false, MODE>(l, s);
 }
 
+template <int W, int L, int K, int MODE, int EPW>
+void launch_tile(const Launch &l, hipStream_t s) {
+    if (l.p.rotation)
+        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, true, MODE, EPW>), dim3(l.blocks), dim3(kWave * kTileWaves),
+                           (TileGeo<W, L, K, true, EPW>::LDS_BLOCK), s, l.p);
+    else
+        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, false, MODE, EPW>), dim3(l.blocks), dim3(kWave * kTileWaves),
+                           (TileGeo<W, L, K, false, EPW>::LDS_BLOCK), s, l.p);
+}
+
 template <int MODE>
 int launch(const Launch &l, hipStream_t s) {
     if (l.lds > (l.fast >= 0 ? 160 : 64) * 1024) return fail(BPP_E_TOOLARGE, "LDS request per workgroup too large");
-    if (l.fast == 0)
-        launch_fast<10, 10, 1, MODE>(l, s);
-    else if (l.fast == 1)
-        launch_fast<20, 20, 1, MODE>(l, s);
-    else if (l.fast == 2)
-        launch_fast<20, 20, 2, MODE>(l, s);
-    else if (l.fast == 3)
-        launch_fast<10, 10, 2, MODE>(l, s);
+    if (l.tile == 0)
+        launch_tile<10, 10, 1, MODE, 4>(l, s);
+    else if (l.tile == 1)
+        launch_tile<20, 20, 1, MODE, 1>(l, s);
+    else if (l.tile == 2)
+        launch_tile<20, 20, 2, MODE, 1>(l, s);
+    else if (l.tile == 3)
+        launch_tile<10, 10, 2, MODE, 4>(l, s);
     else if (l.fast == kRuntimeGeo)
         launch_fast<0, 0, 1, MODE>(l, s);
     else if (l.fast == kRuntimeGeo + 1)
@@ -1780,6 +1804,28 @@ int bpp_set_knobs(const bpp_knobs *k) {
     (void)current_knobs();
     std::lock_guard<std::mutex> lock(g_knob_mutex);
     g_knobs = *k;
+    return 0;
+}
+
+int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation, int32_t out[6]) {
+    if (!out) return fail(BPP_E_BADARG, "bpp_launch_info: NULL");
+    int rc = check_geometry(E, W, L, H, rotation, BPP_RULE_UTILS);
+    if (rc) return rc;
+    const Launch l = configure(E, W, L, H, rotation, BPP_RULE_UTILS);
+    out[0] = l.tile >= 0 ? BPP_KERNEL_TILE : (l.fast >= 0 ? BPP_KERNEL_PREFIX_RT : BPP_KERNEL_CELLSCAN);
+    out[1] = l.tile >= 0 ? kTileGeo[l.tile].K : (l.fast >= 0 ? l.fast - kRuntimeGeo + 1 : 0);
+    out[2] = l.p.epw;
+    out[3] = l.wpb;
+    out[4] = l.blocks;
+    size_t lds = l.lds;
+    if (l.tile >= 0) {
+        const TileGeoEntry &g = kTileGeo[l.tile];
+        const int A = W * L, M = A * (1 + rotation), npass = (A + kWave - 1) / kWave;
+        const int off_mk = round16(g.epw * A), off_rec = round16(off_mk + g.epw * M), off_bal = off_rec + g.epw * (int)sizeof(BinRec);
+        const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
+        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K);
+    }
+    out[5] = (int32_t)lds;
     return 0;
 }
 

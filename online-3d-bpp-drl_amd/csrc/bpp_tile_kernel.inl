@@ -1,0 +1,571 @@
+// bpp_tile_kernel.inl -- the production step/reset/mask kernel for the compile-time geometries (10x10 and 20x20
+// bins), included by bpp_kernels.hip inside its anonymous namespace.  Same algorithm as bpp_fast_kernel (byte
+// tiles in LDS, one deciding wave per workgroup, packed-histogram prefix image, bin-uniform candidate loop) with
+// the instruction count cut where the round-1 counters said it went (the kernel is VALU-issue bound):
+//   * everything that depends only on the lane is a compile-time constant: G = 64 / EPW lanes per bin, a lane
+//     owns quads sl, sl + G, sl + 2G ... of its bin, so every tile / observation / mask access is ONE per-lane
+//     base address plus immediate offsets, and the plane a store belongs to is known per unrolled iteration
+//     (round 1: 12 stores at 25 of 64 lanes for the constant planes, an index division per access);
+//   * the deciding wave spreads the placement window over LPB = 64 / (bins per workgroup) lanes per bin and
+//     merges (max, count) with two shuffles per halving instead of 25 predicated reads in one lane;
+//   * per-orientation constants (thresholds, candidate ranges, the index-decode multiplier from a table in
+//     constant memory) are derived on the scalar unit from the bin's item, not in vector registers;
+//   * the corner-count rule is evaluated on lane masks (scalar and/or), two selects per candidate;
+//   * the uniform-feasible draw of the next action works on the candidate loop's ballots (scalar popcounts,
+//     one mbcnt in the winning pass) instead of re-scanning the LDS mask bytes;
+//   * episode statistics: the (few) finishing lanes add their four values straight into the slot.
+// Reference semantics are cited at the same places as in bpp_fast_kernel.
+
+// ceil(2^22 / n) for n = 1..256 (n = 0 unused): the candidate index decode i = (t * magic) >> 22, see make_ori.
+struct CandMagicTable {
+    uint32_t v[257];
+};
+constexpr CandMagicTable make_cand_magic() {
+    CandMagicTable t{};
+    t.v[0] = 0;
+    for (uint32_t n = 1; n <= 256; ++n) t.v[n] = ((1u << kCandShift) + n - 1u) / n;
+    return t;
+}
+__constant__ const CandMagicTable kCandMagic = make_cand_magic();
+
+constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
+
+constexpr int round16(int v) { return (v + 15) & ~15; }
+
+template <int W, int L, int K, bool ROT, int EPW>
+struct TileGeo {
+    static constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, M4 = M / 4, PW = L + 1, PN = (W + 1) * (L + 1);
+    static constexpr int G = kWave / EPW;              // lanes per bin in a tile wave
+    static constexpr int NB = kTileWaves * EPW;        // bins per workgroup
+    static constexpr int LPB = kWave / NB;             // lanes per bin in the deciding wave
+    static constexpr int NPASS = (A + kWave - 1) / kWave;  // candidate passes per orientation (at most A candidates)
+    static constexpr int OFF_MK = round16(EPW * A);
+    static constexpr int OFF_REC = round16(OFF_MK + EPW * M);
+    static constexpr int OFF_BAL = OFF_REC + EPW * (int)sizeof(BinRec);          // ballots of the candidate passes
+    static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
+    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;
+    static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
+    static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
+    static_assert(G <= A4, "a lane group must not span more than two observation planes per pass");
+    static_assert(NB <= kWave && (EPW & (EPW - 1)) == 0, "bins per workgroup");
+};
+
+template <int W, int L, int K, bool ROT, int MODE, int EPW>
+__global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Params p) {
+    using T = TileGeo<W, L, K, ROT, EPW>;
+    constexpr int A = T::A, A4 = T::A4, M = T::M, M4 = T::M4, PW = T::PW, PN = T::PN, G = T::G, NB = T::NB, LPB = T::LPB;
+    constexpr int NPASS = T::NPASS;
+    constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk_e0 = xcd_block(p.xcd_remap) * NB;   // first bin of this workgroup
+    const int e0 = blk_e0 + wid * EPW;                 // first bin of this wave
+    const int nenv = max(0, min(EPW, p.E - e0));       // workgroup barriers below: no early return
+    const int el = lane / G, sl = lane % G;            // this lane's bin within the wave, position within the bin
+    const bool mine = el < nenv;
+    unsigned char *wb = smem + wid * T::LDS_WAVE;
+    uint8_t *hm = wb;
+    uint32_t *hm32 = (uint32_t *)wb;
+    uint8_t *mk = wb + T::OFF_MK;
+    uint32_t *mk32 = (uint32_t *)mk;
+    BinRec *rec = (BinRec *)(wb + T::OFF_REC);
+    uint64_t *balm = (uint64_t *)(wb + T::OFF_BAL);
+    Ent<K> *P = (Ent<K> *)(wb + T::OFF_P);
+    const uint32_t hclamp = (uint32_t)p.H + 1u;        // heights above H all behave like H+1 (never feasible)
+    constexpr int KQ = (A4 + G - 1) / G;               // tile quads per lane
+    constexpr int KM = (M4 + G - 1) / G;               // mask quads per lane
+
+    if (BPP_ABL(p, 16)) return;
+    // ---- deciding wave: per-bin loads first, their latency overlaps the staging -----------------------
+    const int db = lane / LPB, ql = lane % LPB;        // deciding wave: bin within the workgroup, lane within the bin
+    const int dec_nb = max(0, min(NB, p.E - blk_e0));
+    const bool dactive = db < dec_nb;
+    const int dec_e = blk_e0 + (dactive ? db : 0);
+    bpp_env_state st0;
+    int64_t act0 = 0;
+    if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
+        st0 = p.state[dec_e];
+        act0 = p.actions[dec_e];
+    }
+
+    // ---- phase 1: stage heightmaps as bytes (lane owns quads sl + G*k of bin el) ----------------------
+    if (MODE == kStep) {
+        const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)(e0 + el) * A) + sl;
+        uint32_t v[KQ];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) v[k] = (mine && sl + G * k < A4 && !BPP_ABL(p, 64)) ? gh[G * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = v[k];
+    } else if (MODE == kMaskHmap) {
+        const int4 *gh = (const int4 *)(p.hmap_in + (size_t)(e0 + el) * A) + sl;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            if (mine && sl + G * k < A4) {
+                const int4 v = gh[G * k];
+                hm32[el * A4 + sl + G * k] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) |
+                                             (min((uint32_t)v.z, 255u) << 16) | (min((uint32_t)v.w, 255u) << 24);
+            }
+    } else if (MODE == kMaskObs) {
+        const float4 *go = (const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A) + sl;  // acktr/utils.py:41-47
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            if (mine && sl + G * k < A4) {
+                const float4 v = go[G * k];
+                hm32[el * A4 + sl + G * k] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
+                                             (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;  // space.py:22
+    }
+    __syncthreads();  // wave 0 reads the other waves' tiles below
+
+    // ---- phase 2: per-bin scalar chain in wave 0, LPB lanes per bin -------------------------------------
+    bool fin = false;
+    double fin_ret = 0.0, fin_ratio = 0.0;
+    int fin_len = 0;
+    if (wid == 0 && !BPP_ABL(p, 32)) {
+        const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
+        const int e = dec_e;
+        const int ow = db / EPW, oel = db % EPW;       // owning wave, bin within it
+        unsigned char *ob = smem + ow * T::LDS_WAVE;
+        const uint8_t *ohm = ob + oel * A;
+        BinRec r;
+        r.item = 0;
+        r.place = 0;
+        r.flags = 0;
+        r.any = 0;
+        if (MODE == kStep) {
+            bpp_env_state st = st0;
+            const int64_t act = act0;
+            // binCreator.py:15-18: current / next / first-of-next-episode items come from the state record;
+            // the pool entries the NEXT step needs are fetched speculatively for both outcomes.
+            const int Tn = p.T;
+            int seq_n = st.seq + p.seq_stride;
+            seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
+            int seq_nn = seq_n + p.seq_stride;
+            seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
+            const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
+            const uint32_t sp_ok = p.pool[(size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1)];
+            const uint32_t sp_f1 = p.pool[(size_t)seq_n * Tn + min(1, Tn - 1)];
+            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * Tn];
+            const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
+            int64_t idx = act;                                         // bin3D.py:96-105
+            const bool flag = ROT && idx > A;
+            if (flag) idx -= A;
+            const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
+            bool ok = dactive && idx >= 0 && idx < (int64_t)(W + 1) * L;
+            int lx = 0, ly = 0;
+            if (ok) {
+                lx = (int)idx / L;                                     // space.py:153-156
+                ly = (int)idx - lx * L;
+                ok = (lx + x <= W) && (ly + y <= L);                   // space.py:112-115
+            }
+            int top = 0;
+            if (ok) {   // uniform over the bin's LPB lanes
+                const uint8_t *hb = ohm + lx * L + ly;
+                int mh = 0, ma = 0;                                    // space.py:127-129
+                if (x <= 5 && y <= 5) {
+                    // common item sizes: rows ql, ql + LPB, ... of the window in this lane, predicated reads
+                    constexpr int NR = (5 + LPB - 1) / LPB;
+                    int v[NR][5];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) {
+                            const int a = ql + rr * LPB;
+                            v[rr][b] = (a < x && b < y) ? (int)hb[a * L + b] : -1;
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) mh = max(mh, v[rr][b]);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) ma += (v[rr][b] == mh);
+                } else {
+                    for (int a = ql; a < x; a += LPB)
+                        for (int b = 0; b < y; ++b) {
+                            const int v = hb[a * L + b];
+                            ma = v > mh ? 1 : ma + (v == mh);
+                            mh = max(mh, v);
+                        }
+                }
+                // merge (max, count) over the bin's LPB lanes; every lane ends up with the window's pair
+#pragma unroll
+                for (int d = 1; d < LPB; d <<= 1) {
+                    const int m2 = __shfl_xor(mh, d, kWave), c2 = __shfl_xor(ma, d, kWave);
+                    const int nm = max(mh, m2);
+                    ma = (mh == nm ? ma : 0) + (m2 == nm ? c2 : 0);
+                    mh = nm;
+                }
+                const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
+                const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125
+                Win w;
+                w.mh = mh;
+                w.ma = ma;
+                w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
+                w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
+                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);       // space.py:131-144
+                top = mh + z;                                          // space.py:42-45 with lz = max_h
+            }
+            const int vol = ix * iy * iz;
+            const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;  // bin3D.py:44-46,108-121
+            st.n_boxes += ok ? 1 : 0;
+            st.vol_sum += ok ? vol : 0;
+            st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
+            st.ep_len += 1;
+            const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
+            if (lead) {
+                p.reward[e] = (float)rew;                              // acktr/envs.py:192
+                p.done[e] = ok ? 0 : 1;
+                p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
+                p.ratio[e] = ratio;
+                p.ep_ret[e] = st.ep_ret;
+                p.ep_len[e] = st.ep_len;
+            }
+            fin = lead && !ok;
+            fin_ret = st.ep_ret;
+            fin_ratio = ratio;
+            fin_len = st.ep_len;
+            if (ok) {
+                st.cursor += 1;                                        // bin3D.py:116-117
+                st.item_cur = it_nxt;
+                st.item_next = sp_ok;
+                r.item = it_nxt;
+                r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+                r.flags = 1u | ((uint32_t)top << 8);
+            } else {                                                   // shmem_vec_env.py:128-129
+                st.episode += 1;
+                st.seq = seq_n;
+                st.cursor = 0;
+                st.n_boxes = 0;
+                st.vol_sum = 0;
+                st.ep_ret = 0.0;
+                st.ep_len = 0;
+                st.item_cur = it_rst;
+                st.item_next = sp_f1;
+                st.item_reset = sp_f2;
+                r.item = it_rst;
+                r.flags = 2u;
+            }
+            if (lead) p.state[e] = st;
+        } else if (MODE == kResetInit || MODE == kResetAdvance) {
+            bpp_env_state st;
+            if (MODE == kResetInit) {
+                st.episode = 0;
+                st.seq = (int32_t)(((uint32_t)p.base_mod + (uint32_t)e) % (uint32_t)p.P);
+            } else {
+                st = p.state[e];
+                st.episode += 1;
+                const int sq = st.seq + p.seq_stride;
+                st.seq = sq >= p.P ? sq - p.P : sq;
+            }
+            st.cursor = 0;
+            st.n_boxes = 0;
+            st.vol_sum = 0;
+            st.ep_ret = 0.0;
+            st.ep_len = 0;
+            int sn = st.seq + p.seq_stride;
+            sn = sn >= p.P ? sn - p.P : sn;
+            st.item_cur = p.pool[(size_t)st.seq * p.T];
+            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
+            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.pad = 0;
+            if (lead) p.state[e] = st;
+            r.item = st.item_cur;
+            r.flags = 2u;
+        } else if (MODE == kMaskObs) {
+            const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
+            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
+        } else {
+            const int32_t *it = p.items_in + (size_t)e * 3;
+            r.item = pack_item(it[0], it[1], it[2]);
+        }
+        if (lead) ((BinRec *)(ob + T::OFF_REC))[oel] = r;
+    }
+    __syncthreads();
+    // episode statistics (main.py:159-162): the finishing bins' lead lanes add straight into this workgroup's slot
+    if (MODE == kStep && wid == 0 && p.stats && fin && !BPP_ABL(p, 128)) {
+        double *a = p.stats + 4 * (blockIdx.x & (BPP_STATS_SLOTS - 1));
+        atomicAdd(a + 0, fin_ret);
+        atomicAdd(a + 1, fin_ratio);
+        atomicAdd(a + 2, (double)fin_len);
+        atomicAdd(a + 3, 1.0);
+    }
+
+    BinRec myrec;   // this lane's bin
+    myrec.item = 0;
+    myrec.place = 0;
+    myrec.flags = 0;
+    myrec.any = 0;
+    if (mine) myrec = rec[el];
+
+    if (MODE == kStep) {
+        // ---- phase 2b: apply the placement (space.py:36-46: window := max_h + z), rows over the bin's lanes;
+        // a finished bin restarts from an empty map -----------------------------------------------------
+        if (myrec.flags & 1u) {
+            const int lx = myrec.place & 255u, ly = (myrec.place >> 8) & 255u, x = (myrec.place >> 16) & 255u, y = myrec.place >> 24;
+            uint8_t *hb = hm + el * A + lx * L + ly;
+            const uint8_t top = (uint8_t)(myrec.flags >> 8);
+            for (int a = sl; a < x; a += G)
+                for (int b = 0; b < y; ++b) hb[a * L + b] = top;
+        }
+        if (myrec.flags & 2u) {
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+                if (sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;
+        }
+        wave_sync();
+    }
+
+    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
+        // ---- phase 3: byte heightmap (state) + float32 observation out (bin3D.py:49-66).  The bin's 4A floats
+        // are A quads; lane sl owns quads sl + G*k: the plane of a quad is a compile-time property of k, except
+        // in the (at most three) passes that straddle a plane boundary, where it is a compile-time lane split.
+        if (mine && !BPP_ABL(p, 8)) {
+            uint32_t *gh = (uint32_t *)(p.hmap + (size_t)(e0 + el) * A) + sl;
+            float4 *go = (float4 *)(p.obs + (size_t)(e0 + el) * 4 * A) + sl;
+            const uint32_t item = myrec.item;
+            const float fx = (float)(item & 255u), fy = (float)((item >> 8) & 255u), fz = (float)((item >> 16) & 255u);
+            constexpr int KO = (A + G - 1) / G;
+#pragma unroll
+            for (int k = 0; k < KO; ++k) {
+                const int q = sl + G * k;                // quad within the bin's observation row
+                const int lo = (G * k) / A4, hi = min(3, (G * k + G - 1) / A4);   // folds: G, k, A4 are constants
+                if (q < A) {
+                    const int pl = (lo == hi) ? lo : (q < hi * A4 ? lo : hi);
+                    if (pl == 0) {
+                        const uint32_t v = hm32[el * A4 + q];
+                        gh[G * k] = v;
+                        go[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                (float)(v >> 24));
+                    } else {
+                        const float f = pl == 1 ? fx : (pl == 2 ? fy : fz);
+                        go[G * k] = make_float4(f, f, f, f);
+                    }
+                }
+            }
+        }
+        if (p.mask == nullptr) return;
+    }
+
+    // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
+    if (!BPP_ABL(p, 1)) {
+        if constexpr (EPW == 1) {
+            if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
+        } else {
+            Ent<K> zero;
+#pragma unroll
+            for (int k = 0; k < K; ++k) zero.w[k] = 0;
+            for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
+                const int b = t / (PW + W), r = t - b * (PW + W);
+                P[b * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
+            }
+            for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
+                const int b = t / W, i = t - b * W;
+                const uint8_t *row = hm + b * A + i * L;
+                Ent<K> *pr = P + b * PN + (i + 1) * PW + 1;
+                Ent<K> s = zero;
+                uint32_t hv[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) hv[j] = row[j];
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                    pr[j] = s;
+                }
+            }
+            wave_sync();
+            for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
+                const int b = t / L, j = t - b * L;
+                Ent<K> *pc = P + b * PN + PW + (j + 1);
+                Ent<K> s = zero;
+                constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
+                for (int i0 = 0; i0 < W; i0 += CH) {
+                    Ent<K> v[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
+                        pc[(i0 + i) * PW] = s;
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+
+    // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+        if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
+    wave_sync();
+    const bool draw = MODE == kStep && p.next_action != nullptr;
+    for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
+        const Ent<K> *Pe = P + b * PN;
+        const uint8_t *he = hm + b * A;
+        uint8_t *me = mk + b * M;
+        const uint32_t item = __builtin_amdgcn_readfirstlane(rec[b].item);
+        // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
+        const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
+                           (__builtin_amdgcn_readfirstlane(rec[b].flags) & 2u) != 0u;
+        uint64_t balr[2][BAL_REGS ? NPASS : 1];   // ballots of the passes (scalar registers after unrolling)
+        uint32_t dec_od[2], dec_nj[2];            // per-orientation index decode, kept for the draw
+        int tot = 0;                              // feasible candidates so far (both orientations)
+#pragma unroll
+        for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
+            // per-orientation constants on the scalar unit: the item is wave-uniform
+            const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+            const int x = rot ? iy : ix, y = rot ? ix : iy;
+            const bool valid = x >= 1 && y >= 1 && x <= W && y <= L;
+            const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
+            const uint32_t od = kCandMagic.v[nj];
+            dec_od[rot] = od;
+            dec_nj[rot] = (uint32_t)nj;
+#pragma unroll
+            for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[rot][ps] = 0ull;
+            if (!BAL_REGS) {
+                for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + rot) * NPASS + ps] = 0ull;
+                wave_sync();
+            }
+            if (ROT && rot == 1 && x == y && valid) {
+                // square footprint: the turned item's mask (utils.py:81-89) equals the first half
+#pragma unroll
+                for (int k = 0; k < (A4 + kWave - 1) / kWave; ++k)
+                    if (lane + kWave * k < A4) mk32[b * M4 + A4 + lane + kWave * k] = mk32[b * M4 + lane + kWave * k];
+                if (BAL_REGS) {
+#pragma unroll
+                    for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[1][ps] = balr[0][ps];
+                } else {
+                    wave_sync();
+                    for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + 1) * NPASS + ps] = balm[(b * 2) * NPASS + ps];
+                }
+                tot += tot;
+                continue;
+            }
+            if (!valid) continue;                                       // item does not fit at all
+            const int area = x * y;
+            const int t95 = 19 * area / 20 + 1, t85 = 17 * area / 20 + 1, t50 = area / 2 + 1;
+            const int hz1 = max(p.H - z + 1, 0);
+            const bool big = x > kTileX || y > kTileY;
+            const int o10 = (x - 1) * L, o01 = y - 1;
+            // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
+            auto run = [&](auto big_c, auto empty_c) {
+                constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
+#pragma unroll(BAL_REGS ? NPASS : 1)
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    if (ps * kWave >= nv) break;                        // wave-uniform
+                    const int t = lane + ps * kWave;
+                    bool f = false;
+                    if (t < nv) {
+                        const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
+                        if (EMPTY) {
+                            f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
+                        } else {
+                            const Ent<K> *Pb = Pe + i * PW + j;
+                            int mh, ma;
+                            if (!BIG) {
+                                const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                                Ent<K> h;
+#pragma unroll
+                                for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
+                                top_of<K>(h, mh, ma);
+                            } else {
+                                window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                            }
+                            const uint8_t *hb = he + i * L + j;
+                            const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+                            // utils.py:23-33 on lane masks: all four corners at max_h -> t50, exactly three -> t85
+                            const bool e0c = r00 == mh, e1c = r10 == mh, e2c = r01 == mh, e3c = r11 == mh;
+                            const bool a01 = e0c && e1c, o01c = e0c || e1c, a23 = e2c && e3c, o23 = e2c || e3c;
+                            const bool all4 = a01 && a23, ge3 = (a01 && o23) || (a23 && o01c);
+                            const int thr = all4 ? t50 : (ge3 ? t85 : t95);
+                            f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
+                            if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
+                                const int rm = max(max(r00, r10), max(r01, r11));
+                                f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+                            }
+                        }
+                        me[rot * A + i * L + j] = f ? 1 : 0;
+                    }
+                    const unsigned long long bl = __ballot(f);
+                    tot += __popcll(bl);
+                    if (BAL_REGS) balr[rot][ps] = bl;
+                    else if (lane == 0) balm[(b * 2 + rot) * NPASS + ps] = bl;
+                }
+            };
+            using TT = std::true_type;
+            using FF = std::false_type;
+            if (fresh)
+                run(FF{}, TT{});
+            else if (big)
+                run(TT{}, FF{});
+            else
+                run(FF{}, FF{});
+            wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
+        }
+        if (lane == 0) rec[b].any = tot > 0 ? 1u : 0u;
+
+        // ---- phase 4c (optional): draw the next action uniformly among the feasible entries -------------
+        // Same result as bpp_sample_feasible on the mask this step writes: pick = hash * count >> 32, the
+        // pick-th set entry in index order = the pick-th set ballot bit in pass order (candidates are
+        // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
+        if (draw) {
+            const int e = e0 + b;
+            const uint32_t hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e));
+            if (tot == 0) {
+                if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
+            } else {
+                int rem = (int)__umulhi(hsh, (uint32_t)tot);
+                bool found = false;
+#pragma unroll
+                for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {
+#pragma unroll(BAL_REGS ? NPASS : 1)
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        unsigned long long bl;
+                        if (BAL_REGS) {
+                            bl = balr[rot][ps];
+                        } else {
+                            const uint64_t v = balm[(b * 2 + rot) * NPASS + ps];
+                            bl = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                                 __builtin_amdgcn_readfirstlane((uint32_t)v);
+                        }
+                        const int c = __popcll(bl);
+                        if (!found && rem < c) {
+                            found = true;
+                            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+                            if (((bl >> lane) & 1ull) && (int)below == rem) {
+                                const int t = lane + ps * kWave;
+                                const int i = (int)(((uint32_t)t * dec_od[rot]) >> kCandShift), j = t - i * (int)dec_nj[rot];
+                                p.next_action[e] = (int64_t)(rot * A + i * L + j);
+                            }
+                        }
+                        rem -= found ? 0 : c;
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
+    if (mine && !BPP_ABL(p, 4)) {
+        float4 *gm = (float4 *)(p.mask + (size_t)(e0 + el) * M) + sl;
+        const bool anyf = rec[el].any != 0u;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (sl + G * k < M4) {
+                const uint32_t v = anyf ? mk32[el * M4 + sl + G * k] : 0x01010101u;
+                gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+            }
+    }
+}

@@ -31,7 +31,7 @@ static int fail(int code, const char *msg) {
 int bpp_abi_version(void) { return BPP_ABI_VERSION; }
 const char *bpp_last_error(void) { return g_err; }
 /* the oracle has no launch shapes: the knobs are accepted and remembered, nothing depends on them */
-static bpp_knobs g_knobs = {0, 0, 1, 0, 0, {0, 0, 0}};
+static bpp_knobs g_knobs = {0, 0, 1, 0, 0, 0, {0, 0}};
 int bpp_get_knobs(bpp_knobs *out) {
     if (!out) return fail(BPP_E_BADARG, "bpp_get_knobs: NULL");
     *out = g_knobs;
@@ -40,6 +40,12 @@ int bpp_get_knobs(bpp_knobs *out) {
 int bpp_set_knobs(const bpp_knobs *k) {
     if (!k) return fail(BPP_E_BADARG, "bpp_set_knobs: NULL");
     g_knobs = *k;
+    return 0;
+}
+int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation, int32_t out[6]) {
+    (void)E; (void)W; (void)L; (void)H; (void)rotation;
+    if (!out) return fail(BPP_E_BADARG, "bpp_launch_info: NULL");
+    for (int k = 0; k < 6; ++k) out[k] = -1;   /* the oracle launches nothing */
     return 0;
 }
 int bpp_limits(int32_t out[2]) {

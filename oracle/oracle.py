@@ -38,13 +38,20 @@ class StepOut(ctypes.Structure):
 
 class Knobs(ctypes.Structure):
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
-                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
 
-def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0):
+def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=0):
     """bpp_set_knobs of whatever library this front-end is bound to (meaningful for the emulated product)."""
-    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0)
+    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0, int(legacy_fast))
     _check(lib().bpp_set_knobs(ctypes.byref(k)))
+
+
+def launch_info(E, size, rotation=False):
+    out = (ctypes.c_int32 * 6)()
+    _check(lib().bpp_launch_info(int(E), int(size[0]), int(size[1]), int(size[2]), int(bool(rotation)), out))
+    return [int(v) for v in out]
 
 
 def build(force=False):

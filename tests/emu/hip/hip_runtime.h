@@ -21,6 +21,7 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__
+#define __constant__
 
 struct dim3 {
     unsigned x, y, z;

@@ -11,10 +11,13 @@ from conftest import MASK_CASES, ROLLOUT_CASES, load_golden
 from test_oracle_golden import check_masks, check_rollout
 
 
-@pytest.fixture(params=["fast-asc", "fast-desc", "generic-asc"])
+@pytest.fixture(params=["tile-asc", "tile-desc", "rt-asc", "generic-asc"])
 def variant(request, emu, monkeypatch):
+    """tile: bpp_tile_kernel for the 10x10 / 20x20 bins (other geometries fall through to the runtime-geometry
+    prefix-image kernel); rt: bpp_fast_kernel with runtime geometry for everything it supports; generic: the
+    cell-scan kernel."""
     path, order = request.param.split("-")
-    emu.set_knobs(force_generic=int(path == "generic"))
+    emu.set_knobs(force_generic=int(path == "generic"), legacy_fast=int(path == "rt"))
     monkeypatch.setenv("BPP_EMU_ORDER", "reverse" if order == "desc" else "forward")
     yield request.param
     emu.set_knobs()
@@ -160,3 +163,21 @@ def test_emulated_shard_coordinates(emu, oracle, base, total, P):
         np.testing.assert_array_equal(r[k], o[k], err_msg=k)
     for f in ("seq", "episode", "cursor", "item_cur", "item_next", "item_reset"):
         np.testing.assert_array_equal(env.state[f], ref.state[f], err_msg=f)
+
+
+def test_emulated_kernel_selection(emu):
+    """Default knobs: the BASELINE geometries run the tile kernel, other areas divisible by 4 the runtime-geometry
+    prefix-image kernel, everything else the cell-scan kernel; the knobs reroute as documented."""
+    emu.set_knobs()
+    assert emu.launch_info(65536, (10, 10, 10))[:4] == [2, 1, 4, 4] and emu.launch_info(65536, (10, 10, 10))[4] == 4096
+    assert emu.launch_info(65536, (10, 10, 10), True)[0] == 2 and emu.launch_info(32768, (20, 20, 20))[:3] == [2, 2, 1]
+    assert emu.launch_info(100, (20, 20, 10))[:3] == [2, 1, 1] and emu.launch_info(100, (10, 10, 22))[:2] == [2, 2]
+    assert emu.launch_info(100, (8, 12, 9))[0] == 1 and emu.launch_info(100, (7, 13, 8))[0] == 0
+    assert emu.launch_info(100, (10, 10, 30))[0] == 0
+    emu.set_knobs(legacy_fast=1)
+    assert emu.launch_info(65536, (10, 10, 10))[0] == 1
+    emu.set_knobs(bins_per_wave=2)
+    assert emu.launch_info(65536, (10, 10, 10))[:3] == [1, 1, 2]
+    emu.set_knobs(force_generic=1)
+    assert emu.launch_info(65536, (10, 10, 10))[0] == 0
+    emu.set_knobs()

@@ -20,11 +20,13 @@ def bpp():
     return bpp_amd
 
 
-@pytest.fixture(params=["fast", "generic"])
+@pytest.fixture(params=["tile", "rt", "generic"])
 def kernel_path(request, bpp):
-    """Every geometry with a compiled fast path (packed-histogram prefix image) is also run through
-    the generic cell-scan kernel; geometries without one run the generic kernel twice (cheap)."""
-    old = bpp._lib.set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=int(request.param == "generic"))
+    """tile: the default dispatch (bpp_tile_kernel for the 10x10 / 20x20 bins, the runtime-geometry prefix-image
+    kernel for other areas divisible by 4, the cell-scan kernel otherwise); rt: bpp_fast_kernel with runtime
+    geometry wherever it applies; generic: the cell-scan kernel for everything."""
+    old = bpp._lib.set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=int(request.param == "generic"),
+                             legacy_fast=int(request.param == "rt"))
     yield request.param
     bpp._lib.set_knobs(**old)
 
@@ -86,7 +88,7 @@ GEOMS = [((10, 10, 10), False, 1024, 11), ((10, 10, 10), True, 1000, 12), ((20, 
          ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16),
          ((20, 20, 10), True, 130, 17), ((20, 20, 22), True, 67, 18), ((10, 10, 7), True, 203, 19),
          ((10, 10, 11), False, 50, 20), ((2, 2, 5), True, 40, 21), ((1, 3, 4), False, 33, 22), ((3, 1, 4), True, 20, 23),
-         ((1, 1, 3), True, 17, 24)]
+         ((1, 1, 3), True, 17, 24), ((8, 128, 10), True, 50, 25), ((4, 255, 10), False, 40, 26), ((14, 72, 12), True, 9, 27)]
 
 
 @pytest.mark.parametrize("size,rot,E,seed", GEOMS)
@@ -515,13 +517,14 @@ def _lockstep_all_bins(bpp, oracle, size, rot, E, base, total, P, steps=12, seed
     assert finished > E // 4
 
 
-@pytest.mark.parametrize("path,xcd", [("fast", 1), ("fast", 0), ("generic", 1)])
+@pytest.mark.parametrize("path,xcd", [("tile", 1), ("tile", 0), ("rt", 1), ("generic", 1)])
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 65536), ((10, 10, 10), True, 65536),
                                          ((20, 20, 20), False, 32768)])
 def test_gpu_full_size_every_bin_matches_oracle(bpp, oracle, knobs, size, rot, E, path, xcd):
     """BASELINE.json configs 2-4 at full size, ALL bins compared (not slices): the XCD block remap, tail
     workgroups and middle-of-grid bins are covered on both kernel paths, remap on and off."""
-    knobs(force_generic=int(path == "generic"), xcd_remap=xcd, bins_per_wave=0, waves_per_group=0)
+    knobs(force_generic=int(path == "generic"), legacy_fast=int(path == "rt"), xcd_remap=xcd, bins_per_wave=0, waves_per_group=0)
+    assert bpp._lib.launch_info(E, size, rot)["kernel"] == {"tile": 2, "rt": 1, "generic": 0}[path]
     _lockstep_all_bins(bpp, oracle, size, rot, E, 0, E, 64 if size[0] > 10 else 512)
 
 
