@@ -121,7 +121,8 @@ typedef struct bpp_knobs {
     int32_t ablate;           /* profiling builds only (-DBPP_ENABLE_ABLATION): phase bit mask, else ignored    */
     int32_t legacy_fast;      /* 1 = run the runtime-geometry prefix-image kernel (bpp_fast_kernel) also for the
                                  10x10 / 20x20 bins that have a compiled tile kernel (bpp_tile_kernel)          */
-    int32_t reserved[2];
+    int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = default (4)  */
+    int32_t reserved[1];
 } bpp_knobs;
 int bpp_get_knobs(bpp_knobs *out);
 int bpp_set_knobs(const bpp_knobs *k);
@@ -190,6 +191,22 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
  * (lengths[k] always receives the true length).  Both libraries export it; no GPU is involved. */
 int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
                  int32_t bound_lo, int32_t bound_hi, uint64_t seed0, int32_t threads);
+
+/* CUT-1: restates envs/bpp0/cutCreator.py:32-128 (CuttingBoxCreator: guillotine cuts until
+ * every piece lies inside box_range = {low_x, low_y, low_z, high_x, high_y, high_z}, then repeated random draws
+ * among the pieces whose support is complete).  Sequence k consumes exact re-implementations of
+ * random.Random(seed0 + k) and -- for the rotation coin, np.random.rand() >= 0.5 swaps x and y, :119-125 --
+ * numpy's legacy RandomState(seed0 + k), so it equals what the reference creator yields after
+ * random.seed(s); np.random.seed(s); reset().  Same pool layout and return codes as bpp_gen_cut2; BPP_E_BADARG
+ * also when the reference's own `assert pos_range[0] <= pos_range[1]` would fire.  Seeds must stay below 2^32. */
+int bpp_gen_cut1(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
+                 const int32_t box_range[6], int32_t rotation, uint64_t seed0, int32_t threads);
+
+/* RS: restates envs/bpp0/binCreator.py:24-40 (RandomBoxCreator): row k = the first T-1 draws
+ * box_set[np.random.randint(0, n_box)] of numpy's legacy RandomState(seed0 + k), then the terminator (W,L,H).
+ * box_set: HOST int32 [n_box][3]. */
+int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, const int32_t *box_set, int32_t n_box,
+               uint64_t seed0, int32_t threads);
 
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }

@@ -157,3 +157,157 @@ static int bpp_gen_cut2_range(uint8_t *pool, int32_t *lengths, int k0, int k1, i
     }
     return overflow;
 }
+
+/* ---- numpy legacy RandomState on the same MT19937 (numpy/random/_mt19937.pyx, legacy seeding) ------ */
+/* np.random.seed(int s), 0 <= s < 2^32: mt19937_seed == init_genrand(s) */
+static void bpp_npmt_seed(bpp_mt *r, uint32_t s) { bpp_mt_init_genrand(r, s); }
+/* np.random.rand(): mt19937_next_double */
+static double bpp_npmt_double(bpp_mt *r) {
+    uint32_t a = bpp_mt_u32(r) >> 5, b = bpp_mt_u32(r) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+/* np.random.randint(0, n) (legacy, dtype int64, n - 1 < 2^32): masked rejection on 32-bit draws
+ * (numpy/random/src/distributions/distributions.c: buffered_bounded_masked_uint32) */
+static uint32_t bpp_npmt_below(bpp_mt *r, uint32_t n) {
+    uint32_t rng = n - 1u, mask = rng, v;
+    if (rng == 0) return 0;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    do v = bpp_mt_u32(r) & mask; while (v > rng);
+    return v;
+}
+
+/* ---- envs/bpp0/cutCreator.py:32-128 (CUT-1) --------------------------------------------------------- */
+typedef struct { int x, y, z, lx, ly, lz; } bpp_meta;
+
+/* returns the number of items (writes at most cap), or -1 when the reference itself would fail
+ * (`assert pos_range[0] <= pos_range[1]`, cutCreator.py:74: a piece smaller than the lower bound) */
+static int bpp_cut1_sequence(int W, int L, int H, const int32_t rg[6], int rotation, uint64_t seed, uint8_t *out, int cap) {
+    const int lowv[3] = {rg[0], rg[1], rg[2]}, highv[3] = {rg[3], rg[4], rg[5]};
+    int vol = W * L * H, minv = (lowv[0] < 1 ? 1 : lowv[0]) * (lowv[1] < 1 ? 1 : lowv[1]) * (lowv[2] < 1 ? 1 : lowv[2]);
+    int maxn = vol / minv + 8;
+    bpp_meta *cur = (bpp_meta *)malloc(sizeof(bpp_meta) * (size_t)maxn * 2);
+    bpp_meta *nxt = (bpp_meta *)malloc(sizeof(bpp_meta) * (size_t)maxn * 2);
+    bpp_meta *cand = (bpp_meta *)malloc(sizeof(bpp_meta) * (size_t)maxn * 2);
+    int *plain = (int *)calloc((size_t)W * L, sizeof(int));
+    int nc = 0, nn = 0, ncand = 0, nout = 0, bad = 0;
+    bpp_mt rng, nprng;
+    bpp_mt_seed(&rng, seed);
+    bpp_npmt_seed(&nprng, (uint32_t)seed);
+    cur[nc++] = (bpp_meta){W, L, H, 0, 0, 0};
+    int again = 1;
+    while (again && !bad) {                                    /* _cut_box, :78-95 */
+        again = 0;
+        nn = 0;
+        for (int i = 0; i < nc && !bad; ++i) {
+            bpp_meta b = cur[i];
+            int dim[3] = {b.x, b.y, b.z}, df_list[3], nd = 0;
+            for (int d = 0; d < 3; ++d)
+                if (dim[d] < lowv[d] || dim[d] > highv[d]) df_list[nd++] = d;   /* _check_box, :52-56 */
+            if (nd == 0) { nxt[nn++] = b; continue; }
+            int df = df_list[bpp_mt_below(&rng, (uint32_t)nd)];                 /* random.choice, :66 */
+            int lo = lowv[df], hi = dim[df] - lowv[df];
+            if (lo > hi) { bad = 1; break; }                                    /* assert, :74 */
+            int pos = lo + (int)bpp_mt_below(&rng, (uint32_t)(hi - lo + 1));    /* random.randint(lo, hi), :75 */
+            bpp_meta b1 = b, b2 = b;                                            /* MetaBox.split, :16-26 */
+            if (df == 0) { b1.x = pos; b2.x = b.x - pos; b2.lx = b.lx + pos; }
+            else if (df == 1) { b1.y = pos; b2.y = b.y - pos; b2.ly = b.ly + pos; }
+            else { b1.z = pos; b2.z = b.z - pos; b2.lz = b.lz + pos; }
+            if (nn + 2 > maxn * 2) { bad = 1; break; }
+            nxt[nn++] = b1;
+            nxt[nn++] = b2;
+            again = 1;
+        }
+        bpp_meta *t = cur; cur = nxt; nxt = t;
+        nc = nn;
+    }
+    while (!bad) {
+        /* _add_candidate, :97-106: pieces whose whole footprint is at their base height become drawable */
+        nn = 0;
+        for (int i = 0; i < nc; ++i) {
+            bpp_meta m = cur[i];
+            int ok = 1;
+            for (int a = m.lx; a < m.lx + m.x && ok; ++a)
+                for (int c = m.ly; c < m.ly + m.y; ++c)
+                    if (plain[a * L + c] != m.lz) { ok = 0; break; }
+            if (ok) cand[ncand++] = m; else cur[nn++] = m;
+        }
+        nc = nn;
+        if (ncand == 0) break;                                                  /* generate_box_size, :111-128 */
+        int idx = (int)bpp_mt_below(&rng, (uint32_t)ncand);                     /* random.randint(0, len - 1) */
+        bpp_meta b = cand[idx];
+        memmove(cand + idx, cand + idx + 1, sizeof(bpp_meta) * (size_t)(ncand - idx - 1));   /* candidates.pop(idx) */
+        --ncand;
+        int ox = b.x, oy = b.y;
+        if (rotation && !(bpp_npmt_double(&nprng) < 0.5)) { ox = b.y; oy = b.x; }            /* :119-125 */
+        if (nout < cap) {
+            out[4 * nout] = (uint8_t)ox;
+            out[4 * nout + 1] = (uint8_t)oy;
+            out[4 * nout + 2] = (uint8_t)b.z;
+            out[4 * nout + 3] = 0;
+        }
+        ++nout;
+        for (int a = b.lx; a < b.lx + b.x; ++a)                                  /* _update, :108-109 */
+            for (int c = b.ly; c < b.ly + b.y; ++c) plain[a * L + c] += b.z;
+    }
+    free(cur);
+    free(nxt);
+    free(cand);
+    free(plain);
+    return bad ? -1 : nout;
+}
+
+static int bpp_gen_cut1_args_ok(int n, int T, int W, int L, int H, const int32_t rg[6]) {
+    if (n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || !rg) return 0;
+    for (int d = 0; d < 3; ++d)
+        if (rg[d] < 1 || rg[d + 3] < 2 * rg[d] - 1) return 0;   /* a piece in (high, 2*low) could never be cut into range */
+    if (W < rg[0] || L < rg[1] || H < rg[2]) return 0;
+    return 1;
+}
+
+/* rows k0..k1-1; returns 0, 1 (a sequence does not fit) or 2 (the reference's assert would fire) */
+static int bpp_gen_cut1_range(uint8_t *pool, int32_t *lengths, int k0, int k1, int T, int W, int L, int H, const int32_t rg[6],
+                              int rotation, uint64_t seed0) {
+    int status = 0;
+    for (int k = k0; k < k1; ++k) {
+        uint8_t *row = pool + (size_t)k * T * 4;
+        for (int t = 0; t < T; ++t) {
+            row[4 * t] = (uint8_t)W;
+            row[4 * t + 1] = (uint8_t)L;
+            row[4 * t + 2] = (uint8_t)H;
+            row[4 * t + 3] = 0;
+        }
+        int n = bpp_cut1_sequence(W, L, H, rg, rotation, seed0 + (uint64_t)k, row, T - 1);
+        if (lengths) lengths[k] = n;
+        if (n < 0) status = 2;
+        else if (n > T - 1 && status == 0) status = 1;
+    }
+    return status;
+}
+
+/* ---- envs/bpp0/binCreator.py:24-40 (RS): T-1 items uniform over box_set, then the terminator -------- */
+static void bpp_gen_rs_range(uint8_t *pool, int k0, int k1, int T, int W, int L, int H, const int32_t *box_set, int n_box,
+                             uint64_t seed0) {
+    for (int k = k0; k < k1; ++k) {
+        uint8_t *row = pool + (size_t)k * T * 4;
+        bpp_mt rng;
+        bpp_npmt_seed(&rng, (uint32_t)(seed0 + (uint64_t)k));
+        for (int t = 0; t < T - 1; ++t) {
+            const int32_t *b = box_set + 3 * bpp_npmt_below(&rng, (uint32_t)n_box);   /* np.random.randint(0, len(box_set)) */
+            row[4 * t] = (uint8_t)b[0];
+            row[4 * t + 1] = (uint8_t)b[1];
+            row[4 * t + 2] = (uint8_t)b[2];
+            row[4 * t + 3] = 0;
+        }
+        row[4 * (T - 1)] = (uint8_t)W;
+        row[4 * (T - 1) + 1] = (uint8_t)L;
+        row[4 * (T - 1) + 2] = (uint8_t)H;
+        row[4 * (T - 1) + 3] = 0;
+    }
+}
+
+static int bpp_gen_rs_args_ok(int n, int T, int W, int L, int H, const int32_t *box_set, int n_box) {
+    if (n <= 0 || T < 2 || W <= 0 || L <= 0 || H <= 0 || W > 255 || L > 255 || H > 255 || !box_set || n_box <= 0) return 0;
+    for (int i = 0; i < 3 * n_box; ++i)
+        if (box_set[i] < 1 || box_set[i] > 255) return 0;
+    return 1;
+}

@@ -44,7 +44,7 @@ class Knobs(ctypes.Structure):
     """struct bpp_knobs"""
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
                 ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("tile_groups", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 
 def hipcc():
@@ -122,7 +122,7 @@ def get_knobs():
     """Current launch-shape knobs as a dict (include/bpp_abi.h: bpp_knobs)."""
     k = Knobs()
     check(lib().bpp_get_knobs(ctypes.byref(k)))
-    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate", "legacy_fast")}
+    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate", "legacy_fast", "tile_groups")}
 
 
 def set_knobs(**kw):
@@ -135,7 +135,7 @@ def set_knobs(**kw):
             raise TypeError("unknown knob %r" % (name,))
         new[name] = int(v)
     k = Knobs(new["bins_per_wave"], new["waves_per_group"], new["xcd_remap"], new["force_generic"], new["ablate"],
-              new["legacy_fast"])
+              new["legacy_fast"], new["tile_groups"])
     check(lib().bpp_set_knobs(ctypes.byref(k)))
     return old
 

@@ -1569,6 +1569,7 @@ struct Launch {
     bool vec;
     int fast;  // kRuntimeGeo + K - 1: prefix-image kernel with runtime geometry, -1 = generic kernel
     int tile;  // index into kTileGeo (compile-time geometry, default launch shape), -1 = not the tile kernel
+    int nit;   // tile kernel: groups of bins a wave walks through (1, 2 or 4)
     int wpb;   // waves per workgroup (waves are independent; this only sets the LDS/dispatch granule)
     int blocks;
     size_t lds;
@@ -1578,9 +1579,9 @@ struct Launch {
 // per wave.  Any other bin with W*L % 4 == 0 and H <= 22 -- and these, when the launch-shape knobs are set --
 // runs bpp_fast_kernel with runtime geometry.
 struct TileGeoEntry {
-    int W, L, K, epw;
+    int W, L, K, epw, nit;   // nit: default number of groups per wave of the step kernel
 };
-constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4}, {20, 20, 1, 1}, {20, 20, 2, 1}, {10, 10, 2, 4}};
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 4}, {20, 20, 1, 1, 4}, {20, 20, 2, 1, 4}, {10, 10, 2, 4, 4}};
 constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 
@@ -1605,6 +1606,7 @@ bpp_knobs current_knobs() {
         g_knobs.force_generic = env_int("BPP_FORCE_GENERIC", 0);
         g_knobs.ablate = env_int("BPP_ABLATE", 0);
         g_knobs.legacy_fast = env_int("BPP_LEGACY_FAST", 0);
+        g_knobs.tile_groups = env_int("BPP_TILE_GROUPS", 0);
         g_knobs_init = true;
     }
     return g_knobs;
@@ -1630,6 +1632,7 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
         while (epw > 1 && (size_t)kWavesPerBlock * (epw * (p.A + p.M + 16)) > 32 * 1024) epw >>= 1;
     l.fast = -1;
     l.tile = -1;
+    l.nit = 1;
     const bool gen = kn.force_generic != 0;
     if (!gen && !kn.legacy_fast && kn.bins_per_wave <= 0 && kn.waves_per_group <= 0)
         for (int g = 0; g < kNumTileGeo; ++g)
@@ -1682,11 +1685,12 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     l.blocks = (waves + l.wpb - 1) / l.wpb;
     l.lds = (size_t)l.wpb * p.lds_per_wave;
     if (l.tile >= 0) {   // the tile kernel's launch shape is part of its type; only the grid depends on E
-        const int nb = kTileWaves * kTileGeo[l.tile].epw;
+        l.nit = (kn.tile_groups == 1 || kn.tile_groups == 2 || kn.tile_groups == 4) ? kn.tile_groups : kTileGeo[l.tile].nit;
+        const int nb = kTileWaves * kTileGeo[l.tile].epw * l.nit;   // step kernel; reset / mask kernels: one group
         p.epw = kTileGeo[l.tile].epw;
         l.wpb = kTileWaves;
         l.blocks = (E + nb - 1) / nb;
-        l.lds = 0;       // filled in by launch_tile from TileGeo<...>::LDS_BLOCK
+        l.lds = 0;       // taken from TileGeo<...>::LDS_BLOCK at launch
     }
     return l;
 }
@@ -1715,14 +1719,28 @@ void launch_fast(const Launch &l, hipStream_t s) {
         launch_fast_rot<W, L, K, false, MODE>(l, s);
 }
 
+template <int W, int L, int K, int MODE, int EPW, int NIT>
+void launch_tile_nit(const Launch &l, hipStream_t s) {
+    const int nb = kTileWaves * EPW * NIT;
+    const int blocks = (l.p.E + nb - 1) / nb;
+    if (l.p.rotation)
+        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, true, MODE, EPW, NIT>), dim3(blocks), dim3(kWave * kTileWaves),
+                           (TileGeo<W, L, K, true, EPW, NIT>::LDS_BLOCK), s, l.p);
+    else
+        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, false, MODE, EPW, NIT>), dim3(blocks), dim3(kWave * kTileWaves),
+                           (TileGeo<W, L, K, false, EPW, NIT>::LDS_BLOCK), s, l.p);
+}
+
+// The step kernel is compiled for 1, 2 and 4 groups per wave (l.nit); reset and the mask-only entry points have no
+// per-bin chain worth amortising and always run one group per wave.
 template <int W, int L, int K, int MODE, int EPW>
 void launch_tile(const Launch &l, hipStream_t s) {
-    if (l.p.rotation)
-        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, true, MODE, EPW>), dim3(l.blocks), dim3(kWave * kTileWaves),
-                           (TileGeo<W, L, K, true, EPW>::LDS_BLOCK), s, l.p);
+    if (MODE == kStep && l.nit == 4)
+        launch_tile_nit<W, L, K, MODE, EPW, MODE == kStep ? 4 : 1>(l, s);
+    else if (MODE == kStep && l.nit == 2)
+        launch_tile_nit<W, L, K, MODE, EPW, MODE == kStep ? 2 : 1>(l, s);
     else
-        hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, false, MODE, EPW>), dim3(l.blocks), dim3(kWave * kTileWaves),
-                           (TileGeo<W, L, K, false, EPW>::LDS_BLOCK), s, l.p);
+        launch_tile_nit<W, L, K, MODE, EPW, 1>(l, s);
 }
 
 template <int MODE>
@@ -1818,12 +1836,13 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
     out[3] = l.wpb;
     out[4] = l.blocks;
     size_t lds = l.lds;
-    if (l.tile >= 0) {
+    if (l.tile >= 0) {   // step kernel shape (TileGeo<...>::LDS_BLOCK restated for runtime arguments)
         const TileGeoEntry &g = kTileGeo[l.tile];
-        const int A = W * L, M = A * (1 + rotation), npass = (A + kWave - 1) / kWave;
-        const int off_mk = round16(g.epw * A), off_rec = round16(off_mk + g.epw * M), off_bal = off_rec + g.epw * (int)sizeof(BinRec);
+        const int A = W * L, M = A * (1 + rotation), npass = (A + kWave - 1) / kWave, nbw = g.epw * l.nit;
+        const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M), off_bal = off_rec + nbw * (int)sizeof(BinRec);
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
         lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K);
+        out[2] = nbw;
     }
     out[5] = (int32_t)lds;
     return 0;
@@ -1917,22 +1936,63 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
 
+}  // extern "C" (reopened below: a template cannot have C linkage)
+
+namespace {
+
+// Rows [0, n) split over host threads; fn(k0, k1) returns a status, the maximum is returned.
+template <typename F>
+int run_rows_threaded(int n, int threads, F fn) {
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
+    if (nt > n) nt = n;
+    std::vector<int> status((size_t)nt, 0);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = (int)((int64_t)n * t / nt), k1 = (int)((int64_t)n * (t + 1) / nt);
+        workers.emplace_back([=, &status] { status[(size_t)t] = fn(k0, k1); });
+    }
+    for (auto &th : workers) th.join();
+    int worst = 0;
+    for (int v : status) worst = v > worst ? v : worst;
+    return worst;
+}
+
+}  // namespace
+
+extern "C" {
+
 int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, int32_t bound_lo,
                  int32_t bound_hi, uint64_t seed0, int32_t threads) {
     if (!pool || !bpp_gen_cut2_args_ok(n, T, W, L, H, bound_lo, bound_hi))
         return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument (bin must exceed bound_hi on some side and bound_lo on none)");
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
-    if (nt > n) nt = n;
-    std::vector<int> over((size_t)nt, 0);
-    std::vector<std::thread> pool_threads;
-    for (int t = 0; t < nt; ++t) {
-        const int k0 = (int)((int64_t)n * t / nt), k1 = (int)((int64_t)n * (t + 1) / nt);
-        pool_threads.emplace_back([=, &over] { over[(size_t)t] = bpp_gen_cut2_range(pool, lengths, k0, k1, T, W, L, H, bound_lo, bound_hi, seed0); });
-    }
-    for (auto &th : pool_threads) th.join();
-    for (int t = 0; t < nt; ++t)
-        if (over[(size_t)t]) return fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries");
+    const int st = run_rows_threaded(n, threads, [=](int k0, int k1) {
+        return bpp_gen_cut2_range(pool, lengths, k0, k1, T, W, L, H, bound_lo, bound_hi, seed0);
+    });
+    return st ? fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries") : 0;
+}
+
+int bpp_gen_cut1(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
+                 const int32_t box_range[6], int32_t rotation, uint64_t seed0, int32_t threads) {
+    if (!pool || !bpp_gen_cut1_args_ok(n, T, W, L, H, box_range) || seed0 + (uint64_t)n > (1ull << 32))
+        return fail(BPP_E_BADARG, "bpp_gen_cut1: bad argument (need low >= 1, high >= 2*low - 1, bin >= low, seeds < 2^32)");
+    int32_t rg[6];
+    memcpy(rg, box_range, sizeof rg);
+    const int st = run_rows_threaded(n, threads, [=](int k0, int k1) {
+        return bpp_gen_cut1_range(pool, lengths, k0, k1, T, W, L, H, rg, rotation != 0, seed0);
+    });
+    if (st == 2) return fail(BPP_E_BADARG, "bpp_gen_cut1: a piece fell below the lower bound (the reference asserts here, cutCreator.py:74)");
+    return st ? fail(BPP_E_TOOLARGE, "bpp_gen_cut1: a sequence does not fit in T-1 entries") : 0;
+}
+
+int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, const int32_t *box_set, int32_t n_box,
+               uint64_t seed0, int32_t threads) {
+    if (!pool || !bpp_gen_rs_args_ok(n, T, W, L, H, box_set, n_box) || seed0 + (uint64_t)n > (1ull << 32))
+        return fail(BPP_E_BADARG, "bpp_gen_rs: bad argument (item sides 1..255, seeds < 2^32)");
+    run_rows_threaded(n, threads, [=](int k0, int k1) {
+        bpp_gen_rs_range(pool, k0, k1, T, W, L, H, box_set, n_box, seed0);
+        return 0;
+    });
     return 0;
 }
 

@@ -13,7 +13,12 @@
 //   * the corner-count rule is evaluated on lane masks (scalar and/or), two selects per candidate;
 //   * the uniform-feasible draw of the next action works on the candidate loop's ballots (scalar popcounts,
 //     one mbcnt in the winning pass) instead of re-scanning the LDS mask bytes;
-//   * episode statistics: the (few) finishing lanes add their four values straight into the slot.
+//   * episode statistics: the (few) finishing lanes add their four values straight into the slot;
+//   * a wave owns NIT groups of EPW bins and walks them one after the other: all tiles are staged up front (one
+//     latency for all), wave 0 decides ALL bins of the workgroup in one pass behind ONE pair of barriers (so the
+//     other waves idle once per 4*EPW*NIT bins, not once per 4*EPW), and the stores of group i overlap the
+//     compute of group i+1.  Wave 0 issues its global stores only after the second barrier: the speculative pool
+//     loads they depend on must not hold the other waves up.
 // Reference semantics are cited at the same places as in bpp_fast_kernel.
 
 // ceil(2^22 / n) for n = 1..256 (n = 0 unused): the candidate index decode i = (t * magic) >> 22, see make_ori.
@@ -32,44 +37,43 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
-template <int W, int L, int K, bool ROT, int EPW>
+template <int W, int L, int K, bool ROT, int EPW, int NIT>
 struct TileGeo {
     static constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, M4 = M / 4, PW = L + 1, PN = (W + 1) * (L + 1);
     static constexpr int G = kWave / EPW;              // lanes per bin in a tile wave
-    static constexpr int NB = kTileWaves * EPW;        // bins per workgroup
+    static constexpr int NBW = EPW * NIT;              // bins per wave: NIT groups of EPW bins, one after the other
+    static constexpr int NB = kTileWaves * NBW;        // bins per workgroup
     static constexpr int LPB = kWave / NB;             // lanes per bin in the deciding wave
     static constexpr int NPASS = (A + kWave - 1) / kWave;  // candidate passes per orientation (at most A candidates)
-    static constexpr int OFF_MK = round16(EPW * A);
-    static constexpr int OFF_REC = round16(OFF_MK + EPW * M);
-    static constexpr int OFF_BAL = OFF_REC + EPW * (int)sizeof(BinRec);          // ballots of the candidate passes
+    static constexpr int OFF_MK = round16(NBW * A);                              // after the NBW byte tiles
+    static constexpr int OFF_REC = round16(OFF_MK + EPW * M);                    // mask bytes of the current group
+    static constexpr int OFF_BAL = OFF_REC + NBW * (int)sizeof(BinRec);          // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
-    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;
+    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;                    // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
     static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
     static_assert(G <= A4, "a lane group must not span more than two observation planes per pass");
-    static_assert(NB <= kWave && (EPW & (EPW - 1)) == 0, "bins per workgroup");
+    static_assert(NB <= kWave && LPB >= 1 && (EPW & (EPW - 1)) == 0 && (NIT & (NIT - 1)) == 0, "bins per workgroup");
 };
 
-template <int W, int L, int K, bool ROT, int MODE, int EPW>
+template <int W, int L, int K, bool ROT, int MODE, int EPW, int NIT>
 __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Params p) {
-    using T = TileGeo<W, L, K, ROT, EPW>;
+    using T = TileGeo<W, L, K, ROT, EPW, NIT>;
     constexpr int A = T::A, A4 = T::A4, M = T::M, M4 = T::M4, PW = T::PW, PN = T::PN, G = T::G, NB = T::NB, LPB = T::LPB;
-    constexpr int NPASS = T::NPASS;
+    constexpr int NPASS = T::NPASS, NBW = T::NBW;
     constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk_e0 = xcd_block(p.xcd_remap) * NB;   // first bin of this workgroup
-    const int e0 = blk_e0 + wid * EPW;                 // first bin of this wave
-    const int nenv = max(0, min(EPW, p.E - e0));       // workgroup barriers below: no early return
-    const int el = lane / G, sl = lane % G;            // this lane's bin within the wave, position within the bin
-    const bool mine = el < nenv;
+    const int we0 = blk_e0 + wid * NBW;                // first bin of this wave
+    const int wnenv = max(0, min(NBW, p.E - we0));     // bins of this wave (workgroup barriers below: no early return)
+    const int el = lane / G, sl = lane % G;            // this lane's bin within a group, position within the bin
     unsigned char *wb = smem + wid * T::LDS_WAVE;
-    uint8_t *hm = wb;
-    uint32_t *hm32 = (uint32_t *)wb;
+    uint8_t *hmw = wb;                                 // [NBW][A] byte tiles of all the wave's bins
     uint8_t *mk = wb + T::OFF_MK;
     uint32_t *mk32 = (uint32_t *)mk;
-    BinRec *rec = (BinRec *)(wb + T::OFF_REC);
+    BinRec *recw = (BinRec *)(wb + T::OFF_REC);        // [NBW]
     uint64_t *balm = (uint64_t *)(wb + T::OFF_BAL);
     Ent<K> *P = (Ent<K> *)(wb + T::OFF_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;        // heights above H all behave like H+1 (never feasible)
@@ -89,48 +93,68 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         act0 = p.actions[dec_e];
     }
 
-    // ---- phase 1: stage heightmaps as bytes (lane owns quads sl + G*k of bin el) ----------------------
+    // ---- phase 1: stage the byte tiles of ALL the wave's bins (lane owns quads sl + G*k of bin it*EPW + el) ----
     if (MODE == kStep) {
-        const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)(e0 + el) * A) + sl;
-        uint32_t v[KQ];
+        uint32_t v[NIT][KQ];
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) v[k] = (mine && sl + G * k < A4 && !BPP_ABL(p, 64)) ? gh[G * k] : 0u;
+        for (int it = 0; it < NIT; ++it) {
+            const bool mine = it * EPW + el < wnenv;
+            const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)(we0 + it * EPW + el) * A) + sl;
 #pragma unroll
-        for (int k = 0; k < KQ; ++k)
-            if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = v[k];
-    } else if (MODE == kMaskHmap) {
-        const int4 *gh = (const int4 *)(p.hmap_in + (size_t)(e0 + el) * A) + sl;
+            for (int k = 0; k < KQ; ++k) v[it][k] = (mine && sl + G * k < A4 && !BPP_ABL(p, 64)) ? gh[G * k] : 0u;
+        }
 #pragma unroll
-        for (int k = 0; k < KQ; ++k)
-            if (mine && sl + G * k < A4) {
-                const int4 v = gh[G * k];
-                hm32[el * A4 + sl + G * k] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) |
-                                             (min((uint32_t)v.z, 255u) << 16) | (min((uint32_t)v.w, 255u) << 24);
-            }
-    } else if (MODE == kMaskObs) {
-        const float4 *go = (const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A) + sl;  // acktr/utils.py:41-47
+        for (int it = 0; it < NIT; ++it) {
+            const bool mine = it * EPW + el < wnenv;
+            uint32_t *hm32 = (uint32_t *)(hmw + it * EPW * A);
 #pragma unroll
-        for (int k = 0; k < KQ; ++k)
-            if (mine && sl + G * k < A4) {
-                const float4 v = go[G * k];
-                hm32[el * A4 + sl + G * k] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
-                                             (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
-            }
+            for (int k = 0; k < KQ; ++k)
+                if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = v[it][k];
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < KQ; ++k)
-            if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;  // space.py:22
+        for (int it = 0; it < NIT; ++it) {
+            const bool mine = it * EPW + el < wnenv;
+            const int e0 = we0 + it * EPW;
+            uint32_t *hm32 = (uint32_t *)(hmw + it * EPW * A);
+            if (MODE == kMaskHmap) {
+                const int4 *gh = (const int4 *)(p.hmap_in + (size_t)(e0 + el) * A) + sl;
+#pragma unroll
+                for (int k = 0; k < KQ; ++k)
+                    if (mine && sl + G * k < A4) {
+                        const int4 v = gh[G * k];
+                        hm32[el * A4 + sl + G * k] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) |
+                                                     (min((uint32_t)v.z, 255u) << 16) | (min((uint32_t)v.w, 255u) << 24);
+                    }
+            } else if (MODE == kMaskObs) {
+                const float4 *go = (const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A) + sl;  // acktr/utils.py:41-47
+#pragma unroll
+                for (int k = 0; k < KQ; ++k)
+                    if (mine && sl + G * k < A4) {
+                        const float4 v = go[G * k];
+                        hm32[el * A4 + sl + G * k] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
+                                                     (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KQ; ++k)
+                    if (mine && sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;  // space.py:22
+            }
+        }
     }
     __syncthreads();  // wave 0 reads the other waves' tiles below
 
     // ---- phase 2: per-bin scalar chain in wave 0, LPB lanes per bin -------------------------------------
-    bool fin = false;
+    bool fin = false, out_ok = false, dlead = false;
     double fin_ret = 0.0, fin_ratio = 0.0;
-    int fin_len = 0;
+    float out_rew = 0.0f;
+    int fin_len = 0, out_boxes = 0;
+    bpp_env_state st_out;
     if (wid == 0 && !BPP_ABL(p, 32)) {
         const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
+        dlead = lead;
         const int e = dec_e;
-        const int ow = db / EPW, oel = db % EPW;       // owning wave, bin within it
+        const int ow = db / NBW, oel = db % NBW;       // owning wave, bin within it
         unsigned char *ob = smem + ow * T::LDS_WAVE;
         const uint8_t *ohm = ob + oel * A;
         BinRec r;
@@ -220,14 +244,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
             st.ep_len += 1;
             const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
-            if (lead) {
-                p.reward[e] = (float)rew;                              // acktr/envs.py:192
-                p.done[e] = ok ? 0 : 1;
-                p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
-                p.ratio[e] = ratio;
-                p.ep_ret[e] = st.ep_ret;
-                p.ep_len[e] = st.ep_len;
-            }
+            out_rew = (float)rew;                                      // acktr/envs.py:192
+            out_ok = ok;
+            out_boxes = st.n_boxes;                                    // bin3D.py:111,124
             fin = lead && !ok;
             fin_ret = st.ep_ret;
             fin_ratio = ratio;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 r.item = it_rst;
                 r.flags = 2u;
             }
-            if (lead) p.state[e] = st;
+            st_out = st;   // written behind the second barrier (it waits for the speculative pool loads)
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -289,6 +308,16 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         if (lead) ((BinRec *)(ob + T::OFF_REC))[oel] = r;
     }
     __syncthreads();
+    if (MODE == kStep && wid == 0 && dlead) {   // per-bin outputs and the state record, off the other waves' path
+        const int e = dec_e;
+        p.reward[e] = out_rew;
+        p.done[e] = out_ok ? 0 : 1;
+        p.counter[e] = out_boxes;
+        p.ratio[e] = fin_ratio;
+        p.ep_ret[e] = fin_ret;
+        p.ep_len[e] = fin_len;
+        p.state[e] = st_out;
+    }
     // episode statistics (main.py:159-162): the finishing bins' lead lanes add straight into this workgroup's slot
     if (MODE == kStep && wid == 0 && p.stats && fin && !BPP_ABL(p, 128)) {
         double *a = p.stats + 4 * (blockIdx.x & (BPP_STATS_SLOTS - 1));
@@ -298,274 +327,288 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         atomicAdd(a + 3, 1.0);
     }
 
-    BinRec myrec;   // this lane's bin
-    myrec.item = 0;
-    myrec.place = 0;
-    myrec.flags = 0;
-    myrec.any = 0;
-    if (mine) myrec = rec[el];
+    // ---- the wave's NIT groups of EPW bins, one after the other ------------------------------------------
+    for (int it = 0; it < NIT; ++it) {
+        const int nenv = max(0, min(EPW, wnenv - it * EPW));   // bins of this group
+        if (nenv == 0) break;                                  // wave-uniform
+        const int e0 = we0 + it * EPW;                         // first bin of the group
+        const bool mine = el < nenv;
+        uint8_t *hm = hmw + it * EPW * A;
+        uint32_t *hm32 = (uint32_t *)hm;
+        BinRec *rec = recw + it * EPW;
+        if (it > 0) wave_sync();   // the previous group's mask bytes / prefix image have been consumed
 
-    if (MODE == kStep) {
-        // ---- phase 2b: apply the placement (space.py:36-46: window := max_h + z), rows over the bin's lanes;
-        // a finished bin restarts from an empty map -----------------------------------------------------
-        if (myrec.flags & 1u) {
-            const int lx = myrec.place & 255u, ly = (myrec.place >> 8) & 255u, x = (myrec.place >> 16) & 255u, y = myrec.place >> 24;
-            uint8_t *hb = hm + el * A + lx * L + ly;
-            const uint8_t top = (uint8_t)(myrec.flags >> 8);
-            for (int a = sl; a < x; a += G)
-                for (int b = 0; b < y; ++b) hb[a * L + b] = top;
-        }
-        if (myrec.flags & 2u) {
-#pragma unroll
-            for (int k = 0; k < KQ; ++k)
-                if (sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;
-        }
-        wave_sync();
-    }
+        BinRec myrec;   // this lane's bin
+        myrec.item = 0;
+        myrec.place = 0;
+        myrec.flags = 0;
+        myrec.any = 0;
+        if (mine) myrec = rec[el];
 
-    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
-        // ---- phase 3: byte heightmap (state) + float32 observation out (bin3D.py:49-66).  The bin's 4A floats
-        // are A quads; lane sl owns quads sl + G*k: the plane of a quad is a compile-time property of k, except
-        // in the (at most three) passes that straddle a plane boundary, where it is a compile-time lane split.
-        if (mine && !BPP_ABL(p, 8)) {
-            uint32_t *gh = (uint32_t *)(p.hmap + (size_t)(e0 + el) * A) + sl;
-            float4 *go = (float4 *)(p.obs + (size_t)(e0 + el) * 4 * A) + sl;
-            const uint32_t item = myrec.item;
-            const float fx = (float)(item & 255u), fy = (float)((item >> 8) & 255u), fz = (float)((item >> 16) & 255u);
-            constexpr int KO = (A + G - 1) / G;
-#pragma unroll
-            for (int k = 0; k < KO; ++k) {
-                const int q = sl + G * k;                // quad within the bin's observation row
-                const int lo = (G * k) / A4, hi = min(3, (G * k + G - 1) / A4);   // folds: G, k, A4 are constants
-                if (q < A) {
-                    const int pl = (lo == hi) ? lo : (q < hi * A4 ? lo : hi);
-                    if (pl == 0) {
-                        const uint32_t v = hm32[el * A4 + q];
-                        gh[G * k] = v;
-                        go[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                (float)(v >> 24));
-                    } else {
-                        const float f = pl == 1 ? fx : (pl == 2 ? fy : fz);
-                        go[G * k] = make_float4(f, f, f, f);
-                    }
-                }
+        if (MODE == kStep) {
+            // ---- phase 2b: apply the placement (space.py:36-46: window := max_h + z), rows over the bin's lanes;
+            // a finished bin restarts from an empty map -----------------------------------------------------
+            if (myrec.flags & 1u) {
+                const int lx = myrec.place & 255u, ly = (myrec.place >> 8) & 255u, x = (myrec.place >> 16) & 255u, y = myrec.place >> 24;
+                uint8_t *hb = hm + el * A + lx * L + ly;
+                const uint8_t top = (uint8_t)(myrec.flags >> 8);
+                for (int a = sl; a < x; a += G)
+                    for (int b = 0; b < y; ++b) hb[a * L + b] = top;
             }
-        }
-        if (p.mask == nullptr) return;
-    }
-
-    // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
-    if (!BPP_ABL(p, 1)) {
-        if constexpr (EPW == 1) {
-            if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
-        } else {
-            Ent<K> zero;
-#pragma unroll
-            for (int k = 0; k < K; ++k) zero.w[k] = 0;
-            for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
-                const int b = t / (PW + W), r = t - b * (PW + W);
-                P[b * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
-            }
-            for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
-                const int b = t / W, i = t - b * W;
-                const uint8_t *row = hm + b * A + i * L;
-                Ent<K> *pr = P + b * PN + (i + 1) * PW + 1;
-                Ent<K> s = zero;
-                uint32_t hv[L];
-#pragma unroll
-                for (int j = 0; j < L; ++j) hv[j] = row[j];
-#pragma unroll
-                for (int j = 0; j < L; ++j) {
-                    const Ent<K> c = code_of<K>(min(hv[j], hclamp));
-#pragma unroll
-                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
-                    pr[j] = s;
-                }
-            }
-            wave_sync();
-            for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
-                const int b = t / L, j = t - b * L;
-                Ent<K> *pc = P + b * PN + PW + (j + 1);
-                Ent<K> s = zero;
-                constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
-                for (int i0 = 0; i0 < W; i0 += CH) {
-                    Ent<K> v[CH];
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
-                        pc[(i0 + i) * PW] = s;
-                    }
-                }
+            if (myrec.flags & 2u) {
+    #pragma unroll
+                for (int k = 0; k < KQ; ++k)
+                    if (sl + G * k < A4) hm32[el * A4 + sl + G * k] = 0u;
             }
             wave_sync();
         }
-    }
 
-    // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
-#pragma unroll
-    for (int k = 0; k < KM; ++k)
-        if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
-    wave_sync();
-    const bool draw = MODE == kStep && p.next_action != nullptr;
-    for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
-        const Ent<K> *Pe = P + b * PN;
-        const uint8_t *he = hm + b * A;
-        uint8_t *me = mk + b * M;
-        const uint32_t item = __builtin_amdgcn_readfirstlane(rec[b].item);
-        // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
-        const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
-                           (__builtin_amdgcn_readfirstlane(rec[b].flags) & 2u) != 0u;
-        uint64_t balr[2][BAL_REGS ? NPASS : 1];   // ballots of the passes (scalar registers after unrolling)
-        uint32_t dec_od[2], dec_nj[2];            // per-orientation index decode, kept for the draw
-        int tot = 0;                              // feasible candidates so far (both orientations)
-#pragma unroll
-        for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
-            // per-orientation constants on the scalar unit: the item is wave-uniform
-            const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-            const int x = rot ? iy : ix, y = rot ? ix : iy;
-            const bool valid = x >= 1 && y >= 1 && x <= W && y <= L;
-            const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
-            const uint32_t od = kCandMagic.v[nj];
-            dec_od[rot] = od;
-            dec_nj[rot] = (uint32_t)nj;
-#pragma unroll
-            for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[rot][ps] = 0ull;
-            if (!BAL_REGS) {
-                for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + rot) * NPASS + ps] = 0ull;
+        if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
+            // ---- phase 3: byte heightmap (state) + float32 observation out (bin3D.py:49-66).  The bin's 4A floats
+            // are A quads; lane sl owns quads sl + G*k: the plane of a quad is a compile-time property of k, except
+            // in the (at most three) passes that straddle a plane boundary, where it is a compile-time lane split.
+            if (mine && !BPP_ABL(p, 8)) {
+                uint32_t *gh = (uint32_t *)(p.hmap + (size_t)(e0 + el) * A) + sl;
+                float4 *go = (float4 *)(p.obs + (size_t)(e0 + el) * 4 * A) + sl;
+                const uint32_t item = myrec.item;
+                const float fx = (float)(item & 255u), fy = (float)((item >> 8) & 255u), fz = (float)((item >> 16) & 255u);
+                constexpr int KO = (A + G - 1) / G;
+    #pragma unroll
+                for (int k = 0; k < KO; ++k) {
+                    const int q = sl + G * k;                // quad within the bin's observation row
+                    const int lo = (G * k) / A4, hi = min(3, (G * k + G - 1) / A4);   // folds: G, k, A4 are constants
+                    if (q < A) {
+                        const int pl = (lo == hi) ? lo : (q < hi * A4 ? lo : hi);
+                        if (pl == 0) {
+                            const uint32_t v = hm32[el * A4 + q];
+                            gh[G * k] = v;
+                            go[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                    (float)(v >> 24));
+                        } else {
+                            const float f = pl == 1 ? fx : (pl == 2 ? fy : fz);
+                            go[G * k] = make_float4(f, f, f, f);
+                        }
+                    }
+                }
+            }
+            if (p.mask == nullptr) continue;
+        }
+
+        // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
+        if (!BPP_ABL(p, 1)) {
+            if constexpr (EPW == 1) {
+                if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
+            } else {
+                Ent<K> zero;
+    #pragma unroll
+                for (int k = 0; k < K; ++k) zero.w[k] = 0;
+                for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
+                    const int b = t / (PW + W), r = t - b * (PW + W);
+                    P[b * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
+                }
+                for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
+                    const int b = t / W, i = t - b * W;
+                    const uint8_t *row = hm + b * A + i * L;
+                    Ent<K> *pr = P + b * PN + (i + 1) * PW + 1;
+                    Ent<K> s = zero;
+                    uint32_t hv[L];
+    #pragma unroll
+                    for (int j = 0; j < L; ++j) hv[j] = row[j];
+    #pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+    #pragma unroll
+                        for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                        pr[j] = s;
+                    }
+                }
+                wave_sync();
+                for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
+                    const int b = t / L, j = t - b * L;
+                    Ent<K> *pc = P + b * PN + PW + (j + 1);
+                    Ent<K> s = zero;
+                    constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
+                    for (int i0 = 0; i0 < W; i0 += CH) {
+                        Ent<K> v[CH];
+    #pragma unroll
+                        for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
+    #pragma unroll
+                        for (int i = 0; i < CH; ++i) {
+    #pragma unroll
+                            for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
+                            pc[(i0 + i) * PW] = s;
+                        }
+                    }
+                }
                 wave_sync();
             }
-            if (ROT && rot == 1 && x == y && valid) {
-                // square footprint: the turned item's mask (utils.py:81-89) equals the first half
-#pragma unroll
-                for (int k = 0; k < (A4 + kWave - 1) / kWave; ++k)
-                    if (lane + kWave * k < A4) mk32[b * M4 + A4 + lane + kWave * k] = mk32[b * M4 + lane + kWave * k];
-                if (BAL_REGS) {
-#pragma unroll
-                    for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[1][ps] = balr[0][ps];
-                } else {
-                    wave_sync();
-                    for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + 1) * NPASS + ps] = balm[(b * 2) * NPASS + ps];
-                }
-                tot += tot;
-                continue;
-            }
-            if (!valid) continue;                                       // item does not fit at all
-            const int area = x * y;
-            const int t95 = 19 * area / 20 + 1, t85 = 17 * area / 20 + 1, t50 = area / 2 + 1;
-            const int hz1 = max(p.H - z + 1, 0);
-            const bool big = x > kTileX || y > kTileY;
-            const int o10 = (x - 1) * L, o01 = y - 1;
-            // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
-            auto run = [&](auto big_c, auto empty_c) {
-                constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
-#pragma unroll(BAL_REGS ? NPASS : 1)
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    if (ps * kWave >= nv) break;                        // wave-uniform
-                    const int t = lane + ps * kWave;
-                    bool f = false;
-                    if (t < nv) {
-                        const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
-                        if (EMPTY) {
-                            f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
-                        } else {
-                            const Ent<K> *Pb = Pe + i * PW + j;
-                            int mh, ma;
-                            if (!BIG) {
-                                const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
-                                Ent<K> h;
-#pragma unroll
-                                for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
-                                top_of<K>(h, mh, ma);
-                            } else {
-                                window_top<K>(Pe, PW, i, j, x, y, mh, ma);
-                            }
-                            const uint8_t *hb = he + i * L + j;
-                            const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
-                            // utils.py:23-33 on lane masks: all four corners at max_h -> t50, exactly three -> t85
-                            const bool e0c = r00 == mh, e1c = r10 == mh, e2c = r01 == mh, e3c = r11 == mh;
-                            const bool a01 = e0c && e1c, o01c = e0c || e1c, a23 = e2c && e3c, o23 = e2c || e3c;
-                            const bool all4 = a01 && a23, ge3 = (a01 && o23) || (a23 && o01c);
-                            const int thr = all4 ? t50 : (ge3 ? t85 : t95);
-                            f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
-                            if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
-                                const int rm = max(max(r00, r10), max(r01, r11));
-                                f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
-                            }
-                        }
-                        me[rot * A + i * L + j] = f ? 1 : 0;
-                    }
-                    const unsigned long long bl = __ballot(f);
-                    tot += __popcll(bl);
-                    if (BAL_REGS) balr[rot][ps] = bl;
-                    else if (lane == 0) balm[(b * 2 + rot) * NPASS + ps] = bl;
-                }
-            };
-            using TT = std::true_type;
-            using FF = std::false_type;
-            if (fresh)
-                run(FF{}, TT{});
-            else if (big)
-                run(TT{}, FF{});
-            else
-                run(FF{}, FF{});
-            wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
         }
-        if (lane == 0) rec[b].any = tot > 0 ? 1u : 0u;
 
-        // ---- phase 4c (optional): draw the next action uniformly among the feasible entries -------------
-        // Same result as bpp_sample_feasible on the mask this step writes: pick = hash * count >> 32, the
-        // pick-th set entry in index order = the pick-th set ballot bit in pass order (candidates are
-        // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
-        if (draw) {
-            const int e = e0 + b;
-            const uint32_t hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e));
-            if (tot == 0) {
-                if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
-            } else {
-                int rem = (int)__umulhi(hsh, (uint32_t)tot);
-                bool found = false;
-#pragma unroll
-                for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {
-#pragma unroll(BAL_REGS ? NPASS : 1)
-                    for (int ps = 0; ps < NPASS; ++ps) {
-                        unsigned long long bl;
-                        if (BAL_REGS) {
-                            bl = balr[rot][ps];
-                        } else {
-                            const uint64_t v = balm[(b * 2 + rot) * NPASS + ps];
-                            bl = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-                                 __builtin_amdgcn_readfirstlane((uint32_t)v);
-                        }
-                        const int c = __popcll(bl);
-                        if (!found && rem < c) {
-                            found = true;
-                            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
-                            if (((bl >> lane) & 1ull) && (int)below == rem) {
-                                const int t = lane + ps * kWave;
-                                const int i = (int)(((uint32_t)t * dec_od[rot]) >> kCandShift), j = t - i * (int)dec_nj[rot];
-                                p.next_action[e] = (int64_t)(rot * A + i * L + j);
-                            }
-                        }
-                        rem -= found ? 0 : c;
-                    }
-                }
-            }
-        }
-    }
-    wave_sync();
-
-    // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
-    if (mine && !BPP_ABL(p, 4)) {
-        float4 *gm = (float4 *)(p.mask + (size_t)(e0 + el) * M) + sl;
-        const bool anyf = rec[el].any != 0u;
-#pragma unroll
+        // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
+    #pragma unroll
         for (int k = 0; k < KM; ++k)
-            if (sl + G * k < M4) {
-                const uint32_t v = anyf ? mk32[el * M4 + sl + G * k] : 0x01010101u;
-                gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+            if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
+        wave_sync();
+        const bool draw = MODE == kStep && p.next_action != nullptr;
+        for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
+            const Ent<K> *Pe = P + b * PN;
+            const uint8_t *he = hm + b * A;
+            uint8_t *me = mk + b * M;
+            const uint32_t item = __builtin_amdgcn_readfirstlane(rec[b].item);
+            // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
+            const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
+                               (__builtin_amdgcn_readfirstlane(rec[b].flags) & 2u) != 0u;
+            uint64_t balr[2][BAL_REGS ? NPASS : 1];   // ballots of the passes (scalar registers after unrolling)
+            uint32_t dec_od[2], dec_nj[2];            // per-orientation index decode, kept for the draw
+            int tot = 0;                              // feasible candidates so far (both orientations)
+    #pragma unroll
+            for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
+                // per-orientation constants on the scalar unit: the item is wave-uniform
+                const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+                const int x = rot ? iy : ix, y = rot ? ix : iy;
+                const bool valid = x >= 1 && y >= 1 && x <= W && y <= L;
+                const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
+                const uint32_t od = kCandMagic.v[nj];
+                dec_od[rot] = od;
+                dec_nj[rot] = (uint32_t)nj;
+    #pragma unroll
+                for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[rot][ps] = 0ull;
+                if (!BAL_REGS) {
+                    for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + rot) * NPASS + ps] = 0ull;
+                    wave_sync();
+                }
+                if (ROT && rot == 1 && x == y && valid) {
+                    // square footprint: the turned item's mask (utils.py:81-89) equals the first half
+    #pragma unroll
+                    for (int k = 0; k < (A4 + kWave - 1) / kWave; ++k)
+                        if (lane + kWave * k < A4) mk32[b * M4 + A4 + lane + kWave * k] = mk32[b * M4 + lane + kWave * k];
+                    if (BAL_REGS) {
+    #pragma unroll
+                        for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[1][ps] = balr[0][ps];
+                    } else {
+                        wave_sync();
+                        for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + 1) * NPASS + ps] = balm[(b * 2) * NPASS + ps];
+                    }
+                    tot += tot;
+                    continue;
+                }
+                if (!valid) continue;                                       // item does not fit at all
+                const int area = x * y;
+                const int t95 = 19 * area / 20 + 1, t85 = 17 * area / 20 + 1, t50 = area / 2 + 1;
+                const int hz1 = max(p.H - z + 1, 0);
+                const bool big = x > kTileX || y > kTileY;
+                const int o10 = (x - 1) * L, o01 = y - 1;
+                // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
+                auto run = [&](auto big_c, auto empty_c) {
+                    constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
+    #pragma unroll(BAL_REGS ? NPASS : 1)
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        if (ps * kWave >= nv) break;                        // wave-uniform
+                        const int t = lane + ps * kWave;
+                        bool f = false;
+                        if (t < nv) {
+                            const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
+                            if (EMPTY) {
+                                f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
+                            } else {
+                                const Ent<K> *Pb = Pe + i * PW + j;
+                                int mh, ma;
+                                if (!BIG) {
+                                    const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                                    Ent<K> h;
+    #pragma unroll
+                                    for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
+                                    top_of<K>(h, mh, ma);
+                                } else {
+                                    window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                                }
+                                const uint8_t *hb = he + i * L + j;
+                                const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+                                // utils.py:23-33 on lane masks: all four corners at max_h -> t50, exactly three -> t85
+                                const bool e0c = r00 == mh, e1c = r10 == mh, e2c = r01 == mh, e3c = r11 == mh;
+                                const bool a01 = e0c && e1c, o01c = e0c || e1c, a23 = e2c && e3c, o23 = e2c || e3c;
+                                const bool all4 = a01 && a23, ge3 = (a01 && o23) || (a23 && o01c);
+                                const int thr = all4 ? t50 : (ge3 ? t85 : t95);
+                                f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
+                                if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
+                                    const int rm = max(max(r00, r10), max(r01, r11));
+                                    f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
+                                }
+                            }
+                            me[rot * A + i * L + j] = f ? 1 : 0;
+                        }
+                        const unsigned long long bl = __ballot(f);
+                        tot += __popcll(bl);
+                        if (BAL_REGS) balr[rot][ps] = bl;
+                        else if (lane == 0) balm[(b * 2 + rot) * NPASS + ps] = bl;
+                    }
+                };
+                using TT = std::true_type;
+                using FF = std::false_type;
+                if (fresh)
+                    run(FF{}, TT{});
+                else if (big)
+                    run(TT{}, FF{});
+                else
+                    run(FF{}, FF{});
+                wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
             }
+            if (lane == 0) rec[b].any = tot > 0 ? 1u : 0u;
+
+            // ---- phase 4c (optional): draw the next action uniformly among the feasible entries -------------
+            // Same result as bpp_sample_feasible on the mask this step writes: pick = hash * count >> 32, the
+            // pick-th set entry in index order = the pick-th set ballot bit in pass order (candidates are
+            // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
+            if (draw) {
+                const int e = e0 + b;
+                const uint32_t hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e));
+                if (tot == 0) {
+                    if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
+                } else {
+                    int rem = (int)__umulhi(hsh, (uint32_t)tot);
+                    bool found = false;
+    #pragma unroll
+                    for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {
+    #pragma unroll(BAL_REGS ? NPASS : 1)
+                        for (int ps = 0; ps < NPASS; ++ps) {
+                            unsigned long long bl;
+                            if (BAL_REGS) {
+                                bl = balr[rot][ps];
+                            } else {
+                                const uint64_t v = balm[(b * 2 + rot) * NPASS + ps];
+                                // (the builtin returns a signed int: go through uint32_t, or the low half sign-extends)
+                                const uint32_t vhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                                const uint32_t vlo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+                                bl = ((unsigned long long)vhi << 32) | (unsigned long long)vlo;
+                            }
+                            const int c = __popcll(bl);
+                            if (!found && rem < c) {
+                                found = true;
+                                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+                                if (((bl >> lane) & 1ull) && (int)below == rem) {
+                                    const int t = lane + ps * kWave;
+                                    const int i = (int)(((uint32_t)t * dec_od[rot]) >> kCandShift), j = t - i * (int)dec_nj[rot];
+                                    p.next_action[e] = (int64_t)(rot * A + i * L + j);
+                                }
+                            }
+                            rem -= found ? 0 : c;
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+
+        // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
+        if (mine && !BPP_ABL(p, 4)) {
+            float4 *gm = (float4 *)(p.mask + (size_t)(e0 + el) * M) + sl;
+            const bool anyf = rec[el].any != 0u;
+    #pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (sl + G * k < M4) {
+                    const uint32_t v = anyf ? mk32[el * M4 + sl + G * k] : 0x01010101u;
+                    gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+                }
+        }
     }
 }

@@ -31,7 +31,7 @@ static int fail(int code, const char *msg) {
 int bpp_abi_version(void) { return BPP_ABI_VERSION; }
 const char *bpp_last_error(void) { return g_err; }
 /* the oracle has no launch shapes: the knobs are accepted and remembered, nothing depends on them */
-static bpp_knobs g_knobs = {0, 0, 1, 0, 0, 0, {0, 0}};
+static bpp_knobs g_knobs = {0, 0, 1, 0, 0, 0, 0, {0}};
 int bpp_get_knobs(bpp_knobs *out) {
     if (!out) return fail(BPP_E_BADARG, "bpp_get_knobs: NULL");
     *out = g_knobs;
@@ -463,4 +463,23 @@ int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t 
         return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument");
     return bpp_gen_cut2_range(pool, lengths, 0, n, T, W, L, H, bound_lo, bound_hi, seed0)
                ? fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries") : 0;
+}
+
+int bpp_gen_cut1(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
+                 const int32_t box_range[6], int32_t rotation, uint64_t seed0, int32_t threads) {
+    (void)threads;
+    if (!pool || !bpp_gen_cut1_args_ok(n, T, W, L, H, box_range) || seed0 + (uint64_t)n > (1ull << 32))
+        return fail(BPP_E_BADARG, "bpp_gen_cut1: bad argument");
+    int st = bpp_gen_cut1_range(pool, lengths, 0, n, T, W, L, H, box_range, rotation != 0, seed0);
+    if (st == 2) return fail(BPP_E_BADARG, "bpp_gen_cut1: a piece fell below the lower bound");
+    return st ? fail(BPP_E_TOOLARGE, "bpp_gen_cut1: a sequence does not fit in T-1 entries") : 0;
+}
+
+int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, const int32_t *box_set, int32_t n_box,
+               uint64_t seed0, int32_t threads) {
+    (void)threads;
+    if (!pool || !bpp_gen_rs_args_ok(n, T, W, L, H, box_set, n_box) || seed0 + (uint64_t)n > (1ull << 32))
+        return fail(BPP_E_BADARG, "bpp_gen_rs: bad argument");
+    bpp_gen_rs_range(pool, 0, n, T, W, L, H, box_set, n_box, seed0);
+    return 0;
 }

@@ -39,12 +39,12 @@ class StepOut(ctypes.Structure):
 class Knobs(ctypes.Structure):
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
                 ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("tile_groups", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 
-def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=0):
+def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=0, tile_groups=0):
     """bpp_set_knobs of whatever library this front-end is bound to (meaningful for the emulated product)."""
-    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0, int(legacy_fast))
+    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0, int(legacy_fast), int(tile_groups))
     _check(lib().bpp_set_knobs(ctypes.byref(k)))
 
 

@@ -125,8 +125,9 @@ static inline T shfl_xor(T v, int m, int width, int line) {
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __ballot(p) ((unsigned long long)emu::rendezvous(emu::K_WAVE, emu::OP_BALLOT, __LINE__, (p) ? 1u : 0u, 0))
+// returns a signed int like the real builtin (so that a missing cast sign-extends here as it does on the GPU)
 #define __builtin_amdgcn_readfirstlane(v) \
-    ((uint32_t)emu::rendezvous(emu::K_WAVE, emu::OP_FIRST, __LINE__, (uint64_t)(uint32_t)(v), 0))
+    ((int)(uint32_t)emu::rendezvous(emu::K_WAVE, emu::OP_FIRST, __LINE__, (uint64_t)(uint32_t)(v), 0))
 #define __builtin_amdgcn_readlane(v, l) (emu::shfl((uint32_t)(v), (int)(l), __LINE__))
 #define __shfl(v, src, width) emu::shfl_idx((v), (src), (width), __LINE__)
 #define __shfl_up(v, d, width) emu::shfl_up((v), (d), (width), __LINE__)
