@@ -10,7 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "bpp_kernels.hip")
-LIB = os.path.join(CSRC, "libbpp_hip.so")
+# BPP_HIP_LIB: load another build of the same library (profiling builds of tools/build_ablation.sh); never a fallback
+LIB = os.environ.get("BPP_HIP_LIB") or os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
@@ -20,7 +21,7 @@ RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
-           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2",
+           "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info"]
 
 
@@ -103,6 +104,10 @@ def lib():
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
+        L.bpp_gen_cut1.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32,
+                                                                                     ctypes.c_uint64, ctypes.c_int32]
+        L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
+                                                                          ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.bpp_launch_info.argtypes = [ctypes.c_int32] * 5 + [ctypes.POINTER(ctypes.c_int32)]
         L.bpp_get_knobs.argtypes = [ctypes.POINTER(Knobs)]

@@ -42,8 +42,21 @@
 // then skips individual phases so their cost can be read off rocprofv3 (results are wrong when used).
 #ifdef BPP_ENABLE_ABLATION
 #define BPP_ABL(p, bit) (((p).ablate & (bit)) != 0)
+// Same build: BPP_ABLATE bit 256 makes lane 0 of every wave of every 8th workgroup of bpp_tile_kernel record the
+// shader clock at its phase boundaries (read back with bpp_debug_stamps, tools/phase_timeline.py).
+constexpr int kStampWaves = 4096;
+constexpr int kStampSlots = 16;
+__device__ unsigned long long g_stamps[kStampWaves * kStampSlots];
+#define BPP_STAMP(p, k)                                                                              \
+    do {                                                                                             \
+        if (((p).ablate & 256) && lane == 0 && (blockIdx.x & 7u) == 0u && (blockIdx.x >> 3) * 4 + wid < kStampWaves) \
+            g_stamps[((blockIdx.x >> 3) * 4 + wid) * kStampSlots + (k)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
 #else
 #define BPP_ABL(p, bit) false
+#define BPP_STAMP(p, k) \
+    do {                \
+    } while (0)
 #endif
 
 namespace {
@@ -1824,6 +1837,21 @@ int bpp_set_knobs(const bpp_knobs *k) {
     g_knobs = *k;
     return 0;
 }
+
+#ifdef BPP_ENABLE_ABLATION
+// profiling builds only: copy the phase timestamps to the host (n = number of uint64 values, <= 4096 * 16)
+int bpp_debug_stamps(unsigned long long *host_out, int n, int clear) {
+    if (!host_out || n <= 0 || n > kStampWaves * kStampSlots) return fail(BPP_E_BADARG, "bpp_debug_stamps: bad argument");
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol");
+    if (clear) {
+        std::vector<unsigned long long> z((size_t)kStampWaves * kStampSlots, 0ull);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * 8, 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyToSymbol");
+    }
+    return 0;
+}
+#endif
 
 int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation, int32_t out[6]) {
     if (!out) return fail(BPP_E_BADARG, "bpp_launch_info: NULL");

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     constexpr int KQ = (A4 + G - 1) / G;               // tile quads per lane
     constexpr int KM = (M4 + G - 1) / G;               // mask quads per lane
 
+    BPP_STAMP(p, 0);
     if (BPP_ABL(p, 16)) return;
     // ---- deciding wave: per-bin loads first, their latency overlaps the staging -----------------------
     const int db = lane / LPB, ql = lane % LPB;        // deciding wave: bin within the workgroup, lane within the bin
@@ -142,7 +143,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             }
         }
     }
+    BPP_STAMP(p, 1);
     __syncthreads();  // wave 0 reads the other waves' tiles below
+    BPP_STAMP(p, 2);
 
     // ---- phase 2: per-bin scalar chain in wave 0, LPB lanes per bin -------------------------------------
     bool fin = false, out_ok = false, dlead = false;
@@ -307,7 +310,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
         if (lead) ((BinRec *)(ob + T::OFF_REC))[oel] = r;
     }
+    BPP_STAMP(p, 3);
     __syncthreads();
+    BPP_STAMP(p, 4);
     if (MODE == kStep && wid == 0 && dlead) {   // per-bin outputs and the state record, off the other waves' path
         const int e = dec_e;
         p.reward[e] = out_rew;
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         uint32_t *hm32 = (uint32_t *)hm;
         BinRec *rec = recw + it * EPW;
         if (it > 0) wave_sync();   // the previous group's mask bytes / prefix image have been consumed
+        if (it == 0) BPP_STAMP(p, 5);
 
         BinRec myrec;   // this lane's bin
         myrec.item = 0;
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             wave_sync();
         }
 
+        if (it == 0) BPP_STAMP(p, 6);
         if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
             // ---- phase 3: byte heightmap (state) + float32 observation out (bin3D.py:49-66).  The bin's 4A floats
             // are A quads; lane sl owns quads sl + G*k: the plane of a quad is a compile-time property of k, except
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             if (p.mask == nullptr) continue;
         }
 
+        if (it == 0) BPP_STAMP(p, 7);
         // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
         if (!BPP_ABL(p, 1)) {
             if constexpr (EPW == 1) {
@@ -444,6 +452,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             }
         }
 
+        if (it == 0) BPP_STAMP(p, 8);
         // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
     #pragma unroll
         for (int k = 0; k < KM; ++k)
@@ -599,6 +608,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
         wave_sync();
 
+        if (it == 0) BPP_STAMP(p, 9);
         // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
         if (mine && !BPP_ABL(p, 4)) {
             float4 *gm = (float4 *)(p.mask + (size_t)(e0 + el) * M) + sl;
@@ -610,5 +620,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
                 }
         }
+        if (it == NIT - 1) BPP_STAMP(p, 10);
     }
 }

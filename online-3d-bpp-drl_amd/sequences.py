@@ -200,22 +200,57 @@ def cut1_sequence(container_size, box_range, rng, rotation=False, np_rng=None):
     return seq
 
 
-def cut1_pool(container_size, n, seed=0, box_range=(2, 2, 2, 5, 5, 5), rotation=False, T=None):
+def cut1_pool(container_size, n, seed=0, box_range=(2, 2, 2, 5, 5, 5), rotation=False, T=None, native=True, threads=0):
+    """P = n CUT-1 sequences; sequence k consumes random.Random(seed + k) and -- for the rotation coin -- numpy's
+    legacy RandomState(seed + k), i.e. what the reference's CuttingBoxCreator yields after random.seed(s);
+    np.random.seed(s); reset().  `native=True`: the library's multithreaded C++ generator (bpp_gen_cut1, exact
+    re-implementations of both streams); `native=False`: the Python restatement above."""
+    if native:
+        return _pool_native("cut1", container_size, n, seed, T, threads, box_range=box_range, rotation=rotation)
     seqs = [cut1_sequence(container_size, box_range, random.Random(seed + k), rotation,
                           np.random.RandomState(seed + k) if rotation else None) for k in range(n)]
     return pad_pool(seqs, container_size, T)
 
 
-def rs_pool(container_size, n, length, seed=0, box_set=None):
-    """RS sequences: items uniform over `box_set` (default {2..5}^3, acktr/arguments.py:122-128,
-    envs/bpp0/binCreator.py:24-40).  Distribution parity only (the reference draws from the global
-    numpy RNG one item at a time)."""
+DEFAULT_BOX_SET = [(i, j, k) for i in range(2, 6) for j in range(2, 6) for k in range(2, 6)]   # acktr/arguments.py:122-128
+
+
+def rs_pool(container_size, n, length, seed=0, box_set=None, native=True, threads=0):
+    """RS sequences (envs/bpp0/binCreator.py:24-40): row k = the first `length` draws
+    box_set[np.random.randint(0, len(box_set))] after np.random.seed(seed + k), then the terminator.  `native=True`:
+    the library's generator (bpp_gen_rs, numpy's legacy MT19937 stream re-implemented); `native=False`: numpy itself."""
     if box_set is None:
-        box_set = [(i, j, k) for i in range(2, 6) for j in range(2, 6) for k in range(2, 6)]
-    rng = np.random.RandomState(seed)
-    box_set = np.asarray(box_set, dtype=np.int64)
-    idx = rng.randint(0, len(box_set), size=(n, length))
+        box_set = DEFAULT_BOX_SET
+    if native:
+        return _pool_native("rs", container_size, n, seed, length + 1, threads, box_set=box_set)
+    bs = np.asarray(box_set, dtype=np.int64)
     pool = np.zeros((n, length + 1, 4), np.uint8)
-    pool[:, :length, :3] = box_set[idx]
+    for k in range(n):
+        rng = np.random.RandomState(seed + k)
+        pool[k, :length, :3] = bs[[rng.randint(0, len(bs)) for _ in range(length)]]
     pool[:, length, :3] = container_size
+    return pool
+
+
+def _pool_native(kind, container_size, n, seed, T, threads, box_range=None, rotation=False, box_set=None):
+    import ctypes
+    from . import _lib
+    W, L, H = (int(v) for v in container_size)
+    lib = _lib.lib()
+    if kind == "rs":
+        bs = np.ascontiguousarray(np.asarray(box_set, dtype=np.int32).reshape(-1, 3))
+        pool = np.zeros((n, T, 4), np.uint8)
+        _lib.check(lib.bpp_gen_rs(pool.ctypes.data, n, T, W, L, H, bs.ctypes.data, bs.shape[0], int(seed), int(threads)))
+        return pool
+    rg = np.ascontiguousarray(np.asarray(box_range, dtype=np.int32).reshape(6))
+    cap = T if T is not None else W * L * H // max(1, int(rg[0]) * int(rg[1]) * int(rg[2])) + 2
+    pool = np.zeros((n, cap, 4), np.uint8)
+    lengths = np.zeros(n, np.int32)
+    rc = lib.bpp_gen_cut1(pool.ctypes.data, lengths.ctypes.data, n, cap, W, L, H, rg.ctypes.data, int(bool(rotation)), int(seed),
+                          int(threads))
+    if rc == -2 and T is not None:
+        raise ValueError("a sequence has %d items, pool rows hold %d + terminator" % (int(lengths.max()), T - 1))
+    _lib.check(rc)
+    if T is None:
+        pool = np.ascontiguousarray(pool[:, :int(lengths.max()) + 1])
     return pool
