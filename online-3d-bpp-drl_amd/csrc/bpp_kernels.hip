@@ -1594,7 +1594,7 @@ struct Launch {
 struct TileGeoEntry {
     int W, L, K, epw, nit;   // nit: default number of groups per wave of the step kernel
 };
-constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 4}, {20, 20, 1, 1, 4}, {20, 20, 2, 1, 4}, {10, 10, 2, 4, 4}};
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1}, {20, 20, 1, 1, 1}, {20, 20, 2, 1, 1}, {10, 10, 2, 4, 1}};
 constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 

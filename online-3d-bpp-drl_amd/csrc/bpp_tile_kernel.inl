@@ -33,6 +33,17 @@ constexpr CandMagicTable make_cand_magic() {
 }
 __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
+// Integer thresholds of the ratio tests per window area: t95 | t85 << 16, t = floor(k*area/20) + 1.
+struct ThresholdTable {
+    uint32_t v[kMaxArea + 1];
+};
+constexpr ThresholdTable make_thresholds() {
+    ThresholdTable t{};
+    for (uint32_t a = 0; a <= (uint32_t)kMaxArea; ++a) t.v[a] = (19u * a / 20u + 1u) | ((17u * a / 20u + 1u) << 16);
+    return t;
+}
+__constant__ const ThresholdTable kThresholds = make_thresholds();
+
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
@@ -154,6 +165,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     int fin_len = 0, out_boxes = 0;
     bpp_env_state st_out;
     if (wid == 0 && !BPP_ABL(p, 32)) {
+        __builtin_amdgcn_s_setprio(3);                 // the other waves of the workgroup wait for this chain
         const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
         dlead = lead;
         const int e = dec_e;
@@ -309,6 +321,23 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             r.item = pack_item(it[0], it[1], it[2]);
         }
         if (lead) ((BinRec *)(ob + T::OFF_REC))[oel] = r;
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // work that does not depend on the decisions, done by the waiting waves while wave 0 decides: clear the first
+    // group's mask bytes and the zero row / column of the prefix image (never written again)
+    {
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
+        if constexpr (EPW > 1) {
+            Ent<K> zero;
+#pragma unroll
+            for (int k = 0; k < K; ++k) zero.w[k] = 0;
+            for (int t = lane; t < EPW * (PW + W); t += kWave) {
+                const int b = t / (PW + W), r = t - b * (PW + W);
+                P[b * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
+            }
+        }
     }
     BPP_STAMP(p, 3);
     __syncthreads();
@@ -407,13 +436,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             if constexpr (EPW == 1) {
                 if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
             } else {
-                Ent<K> zero;
-    #pragma unroll
+                Ent<K> zero;   // (row 0 and column 0 of every image were cleared before the second barrier)
+#pragma unroll
                 for (int k = 0; k < K; ++k) zero.w[k] = 0;
-                for (int t = lane; t < nenv * (PW + W); t += kWave) {          // row 0 and column 0
-                    const int b = t / (PW + W), r = t - b * (PW + W);
-                    P[b * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
-                }
                 for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
                     const int b = t / W, i = t - b * W;
                     const uint8_t *row = hm + b * A + i * L;
@@ -454,9 +479,11 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
 
         if (it == 0) BPP_STAMP(p, 8);
         // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
-    #pragma unroll
-        for (int k = 0; k < KM; ++k)
-            if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
+        if (it > 0) {   // (the first group's mask bytes were cleared before the second barrier)
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
+        }
         wave_sync();
         const bool draw = MODE == kStep && p.next_action != nullptr;
         for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 // per-orientation constants on the scalar unit: the item is wave-uniform
                 const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
                 const int x = rot ? iy : ix, y = rot ? ix : iy;
-                const bool valid = x >= 1 && y >= 1 && x <= W && y <= L;
+                const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
                 const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
                 const uint32_t od = kCandMagic.v[nj];
                 dec_od[rot] = od;
@@ -503,7 +530,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 }
                 if (!valid) continue;                                       // item does not fit at all
                 const int area = x * y;
-                const int t95 = 19 * area / 20 + 1, t85 = 17 * area / 20 + 1, t50 = area / 2 + 1;
+                const uint32_t thr2 = kThresholds.v[area];
+                const int t95 = thr2 & 0xffffu, t85 = thr2 >> 16, t50 = (area >> 1) + 1;
                 const int hz1 = max(p.H - z + 1, 0);
                 const bool big = x > kTileX || y > kTileY;
                 const int o10 = (x - 1) * L, o01 = y - 1;

@@ -124,6 +124,7 @@ static inline T shfl_xor(T v, int m, int width, int line) {
 #define __builtin_amdgcn_wave_barrier() ((void)emu::rendezvous(emu::K_WAVE, emu::OP_SYNC, __LINE__, 0, 0))
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __ballot(p) ((unsigned long long)emu::rendezvous(emu::K_WAVE, emu::OP_BALLOT, __LINE__, (p) ? 1u : 0u, 0))
 // returns a signed int like the real builtin (so that a missing cast sign-extends here as it does on the GPU)
 #define __builtin_amdgcn_readfirstlane(v) \

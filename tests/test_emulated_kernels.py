@@ -11,14 +11,14 @@ from conftest import MASK_CASES, ROLLOUT_CASES, load_golden
 from test_oracle_golden import check_masks, check_rollout
 
 
-@pytest.fixture(params=["tile-asc", "tile-desc", "tile1-asc", "tile2-desc", "rt-asc", "generic-asc"])
+@pytest.fixture(params=["tile-asc", "tile-desc", "tile4-asc", "tile2-desc", "rt-asc", "generic-asc"])
 def variant(request, emu, monkeypatch):
     """tile: bpp_tile_kernel for the 10x10 / 20x20 bins (other geometries fall through to the runtime-geometry
     prefix-image kernel); rt: bpp_fast_kernel with runtime geometry for everything it supports; generic: the
     cell-scan kernel."""
     path, order = request.param.split("-")
     emu.set_knobs(force_generic=int(path == "generic"), legacy_fast=int(path == "rt"),
-                  tile_groups={"tile1": 1, "tile2": 2}.get(path, 0))
+                  tile_groups={"tile4": 4, "tile2": 2}.get(path, 0))
     monkeypatch.setenv("BPP_EMU_ORDER", "reverse" if order == "desc" else "forward")
     yield request.param
     emu.set_knobs()
@@ -170,9 +170,9 @@ def test_emulated_kernel_selection(emu):
     """Default knobs: the BASELINE geometries run the tile kernel, other areas divisible by 4 the runtime-geometry
     prefix-image kernel, everything else the cell-scan kernel; the knobs reroute as documented."""
     emu.set_knobs()
-    assert emu.launch_info(65536, (10, 10, 10))[:4] == [2, 1, 16, 4] and emu.launch_info(65536, (10, 10, 10))[4] == 1024
-    assert emu.launch_info(65536, (10, 10, 10), True)[0] == 2 and emu.launch_info(32768, (20, 20, 20))[:3] == [2, 2, 4]
-    assert emu.launch_info(100, (20, 20, 10))[:3] == [2, 1, 4] and emu.launch_info(100, (10, 10, 22))[:2] == [2, 2]
+    assert emu.launch_info(65536, (10, 10, 10))[:4] == [2, 1, 4, 4] and emu.launch_info(65536, (10, 10, 10))[4] == 4096
+    assert emu.launch_info(65536, (10, 10, 10), True)[0] == 2 and emu.launch_info(32768, (20, 20, 20))[:3] == [2, 2, 1]
+    assert emu.launch_info(100, (20, 20, 10))[:3] == [2, 1, 1] and emu.launch_info(100, (10, 10, 22))[:2] == [2, 2]
     assert emu.launch_info(100, (8, 12, 9))[0] == 1 and emu.launch_info(100, (7, 13, 8))[0] == 0
     assert emu.launch_info(100, (10, 10, 30))[0] == 0
     emu.set_knobs(legacy_fast=1)
