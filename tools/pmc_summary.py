@@ -13,8 +13,8 @@ for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
         k = row["Kernel_Name"]
         if ("bpp_kernel<" in k or "bpp_fast_kernel<" in k) and k.split(">(")[0].endswith(", 0"):
             k = "step"      # MODE == kStep is the last template argument
-        elif "bpp_tile_kernel<" in k and k.split(">(")[0].split(",")[-2].strip() == "0":
-            k = "step"      # bpp_tile_kernel<W, L, K, ROT, MODE, EPW>
+        elif "bpp_tile_kernel<" in k and k.split("bpp_tile_kernel<")[1].split(">(")[0].split(",")[4].strip() == "0":
+            k = "step"      # bpp_tile_kernel<W, L, K, ROT, MODE, EPW, NIT>
         else:
             k = "sample" if "sample_kernel" in k else ("stats" if "stats_kernel" in k else None)
         if k is None:
