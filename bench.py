@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--pool-file", default=None,
                     help="npz with a uint8 [P][T][4] `pool` array instead of generated sequences, e.g. "
                          "tests/golden/cut2_dataset_10.npz = the reference's dataset/cut_2.pt (2100 sequences)")
+    ap.add_argument("--stream", action="store_true",
+                    help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
+                         "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: enough "
                          "repetitions for >= 100 ms of timed work, at most 25, so that a small --steps is not a 1 ms sample)")
@@ -162,7 +165,7 @@ def main():
         import numpy as np
         pool = np.load(args.pool_file)["pool"]
     else:
-        pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)   # identical on every rank
+        pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)   # identical on every rank (cpu_baseline uses it too)
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline:
         # before the HIP runtime is initialised in this process: the baseline forks one worker per core
@@ -190,8 +193,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=pool, device=device,
-                            env_id_base=rank * E, env_id_total=world * E)
+    env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=None if args.stream else pool, device=device,
+                            env_id_base=rank * E, env_id_total=world * E,
+                            stream=dict(bound=(2, 5), seed=0, depth=8, refill_every=5) if args.stream else None)
     stats = bpp_amd.EpisodeStats(device)
     actions = torch.empty(E, dtype=torch.int64, device=device)
     env.reset()
@@ -256,9 +260,9 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     if rank == 0:
-        headline = size == (10, 10, 10) and not args.rotation and E == 65536
-        metric = "env steps/sec (whole node), %dx%dx%d bin%s, %d envs per GPU; bit-exact mask vs ref" % (
-            size + (" + rotation" if args.rotation else "", E))
+        headline = size == (10, 10, 10) and not args.rotation and E == 65536 and not args.stream
+        metric = "env steps/sec (whole node), %dx%dx%d bin%s, %d envs per GPU%s; bit-exact mask vs ref" % (
+            size + (" + rotation" if args.rotation else "", E, ", endless device-generated CUT-2 supply" if args.stream else ""))
         if headline:    # BASELINE.json's metric string belongs to its own workload only
             try:
                 metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -283,7 +287,8 @@ def main():
             "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
                                    % (size + (" + rotation" if args.rotation else "", E)),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
-                       "pool_source": args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)",
+                       "pool_source": ("device stream: random.Random(g) per bin, refill every 5 lock-steps (bpp_stream)" if args.stream
+                                       else args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)"),
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s%s)"
                                    % (world, "RCCL" if backend == "nccl" else backend,
                                       "" if use_pg else ", no process group at 1 rank"),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 5
+#define BPP_ABI_VERSION 6
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -85,7 +85,44 @@ typedef struct bpp_batch {
     double *stats;         /* NULL, or [BPP_STATS_SLOTS][4] episode statistics accumulated by bpp_step
                               (same four sums as bpp_episode_stats, spread over slots to keep the
                               float64 atomics uncontended; the reader sums over the slot axis)    */
+    int32_t pool_mode;     /* BPP_POOL_STATIC: the row rule above.  BPP_POOL_RING: seq_pool is the ring of a
+                              bpp_stream, pool_size = depth * num_envs, episode k of LOCAL bin e plays row
+                              (k mod depth) * num_envs + e, refilled by bpp_stream_refill                */
+    int32_t reserved0;
 } bpp_batch;
+
+#define BPP_POOL_STATIC 0
+#define BPP_POOL_RING   1
+
+/* Endless CUT-2 item supply generated on the device (removes the finite pool).  The reference
+ * draws one sequence after the other from the worker's `random` stream (envs/bpp0/mdCreator.py:147-166).  Here
+ * every bin owns an exact random.Random(seed0 + global bin id) (MT19937 state in device memory) and episode k of
+ * the bin plays the k-th sequence that stream yields through the reference creator.  `ring` holds `depth` rows per
+ * bin; bpp_stream_refill cuts new sequences into the rows of episodes the bin has finished, so that `depth`
+ * episodes are available from the current one.  A step reads rows up to two episodes ahead and a bin can finish at
+ * most one episode per step: refill at least every depth - 3 lock-steps.  Rows are padded with the terminator
+ * (W,L,H); a sequence longer than pool_len - 1 is truncated and counted in `overflow` (size pool_len as
+ * W*L*H / bound_lo^3 + 1 to make that impossible). */
+typedef struct bpp_stream {
+    int32_t num_envs;      /* E                                                                    */
+    int32_t depth;         /* D >= 4: ring rows per bin                                           */
+    int32_t pool_len;      /* T: entries per row                                                  */
+    int32_t W, L, H;
+    int32_t bound_lo, bound_hi;   /* MDlayerBoxCreator(container_size, [bound_lo, bound_hi])      */
+    int64_t env_id_base;   /* global id of local bin 0                                            */
+    uint64_t seed0;
+    uint8_t *ring;         /* [D][E][T][4] == bpp_batch.seq_pool                                   */
+    uint32_t *mt;          /* [625][E] generator state (opaque)                                    */
+    void *work;            /* [W*L*H / bound_lo^3 + 8][E] 8-byte entries: pending boxes (opaque)   */
+    int32_t *gen_next;     /* [E] next episode index to be generated                               */
+    const bpp_env_state *state; /* [E] == bpp_batch.state (read: episode)                          */
+    int32_t *overflow;     /* NULL or [1]: incremented per truncated sequence                      */
+} bpp_stream;
+
+/* Seed every bin's generator; gen_next = 0.  Call once, then bpp_stream_refill, then bpp_reset. */
+int bpp_stream_init(const bpp_stream *s, void *stream);
+/* Generate until gen_next[e] == state[e].episode + depth for every bin (state must be initialised or zero). */
+int bpp_stream_refill(const bpp_stream *s, void *stream);
 
 /* Outputs of one lock-step.  Layout = what VecPyTorch hands the ACKTR loop (acktr/envs.py:170-193)
  * plus the location mask the loop builds per observation (main.py:122-129,163-169). */
@@ -215,6 +252,11 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
  * actions taken. */
 int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
                         uint64_t step0, int32_t nsteps, void *stream);
+
+/* bpp_rollout_uniform over a ring pool: additionally calls bpp_stream_refill(s) after every `refill_every`
+ * lock-steps (1 <= refill_every <= depth - 3). */
+int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
+                               uint64_t step0, int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream);
 
 /* Device-side replacement of the training loop's per-bin `infos` scan (main.py:159-162: for every
  * finished episode append info['episode']['r'] and info['ratio'] to the logging deques):

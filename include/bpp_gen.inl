@@ -68,14 +68,13 @@ static int bpp_cmp_low(const void *a, const void *b) {  /* stable sort by low_bo
     return p->high < q->high ? -1 : (p->high > q->high ? 1 : 0);  /* `high` temporarily holds the original index */
 }
 
-/* returns the number of items; writes at most cap of them */
-static int bpp_cut2_sequence(int W, int L, int H, int lo, int hi, uint64_t seed, uint8_t *out, int cap) {
+/* one sequence from a running random.Random stream; returns the number of items, writes at most cap of them */
+static int bpp_cut2_from_stream(bpp_mt *rngp, int W, int L, int H, int lo, int hi, uint8_t *out, int cap) {
     int vol = W * L * H, maxn = vol / (lo * lo * lo) + 8;
     bpp_cut *valid = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn);
     bpp_cut *inv = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn * 2);
     int nv = 0, ni = 0;
-    bpp_mt rng;
-    bpp_mt_seed(&rng, seed);
+#define rng (*rngp)
     inv[ni++] = (bpp_cut){W, L, H, 0, H};
     while (ni) {
         int i = 0;
@@ -126,7 +125,15 @@ static int bpp_cut2_sequence(int W, int L, int H, int lo, int hi, uint64_t seed,
     }
     free(valid);
     free(inv);
+#undef rng
     return nv;
+}
+
+/* sequence of a fresh random.Random(seed) */
+static int bpp_cut2_sequence(int W, int L, int H, int lo, int hi, uint64_t seed, uint8_t *out, int cap) {
+    bpp_mt r;
+    bpp_mt_seed(&r, seed);
+    return bpp_cut2_from_stream(&r, W, L, H, lo, hi, out, cap);
 }
 
 /* Arguments the reference itself cannot handle: a bin already inside the bounds, or with a side below

@@ -13,16 +13,17 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 # BPP_HIP_LIB: load another build of the same library (profiling builds of tools/build_ablation.sh); never a fallback
 LIB = os.environ.get("BPP_HIP_LIB") or os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
-DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
+DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
-           "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info"]
+           "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_init", "bpp_stream_refill",
+           "bpp_rollout_uniform_stream"]
 
 
 class Batch(ctypes.Structure):
@@ -31,7 +32,18 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p)]
+                ("stats", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+
+
+class Stream(ctypes.Structure):
+    """struct bpp_stream"""
+    _fields_ = [("num_envs", ctypes.c_int32), ("depth", ctypes.c_int32), ("pool_len", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("L", ctypes.c_int32), ("H", ctypes.c_int32), ("bound_lo", ctypes.c_int32), ("bound_hi", ctypes.c_int32),
+                ("env_id_base", ctypes.c_int64), ("seed0", ctypes.c_uint64), ("ring", ctypes.c_void_p), ("mt", ctypes.c_void_p),
+                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p)]
+
+
+POOL_STATIC, POOL_RING = 0, 1
 
 
 class StepOut(ctypes.Structure):
@@ -109,6 +121,11 @@ def lib():
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_stream_init.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
+        L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
+        L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
+                                                 ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
+                                                 ctypes.c_void_p]
         L.bpp_launch_info.argtypes = [ctypes.c_int32] * 5 + [ctypes.POINTER(ctypes.c_int32)]
         L.bpp_get_knobs.argtypes = [ctypes.POINTER(Knobs)]
         L.bpp_set_knobs.argtypes = [ctypes.POINTER(Knobs)]

@@ -1204,6 +1204,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
 }
 
 #include "bpp_tile_kernel.inl"
+#include "bpp_stream_gen.inl"
 
 // Sub-groups of 16 lanes per bin (4 bins per wave): each lane owns `per` consecutive float4 quads of
 // the bin's mask row (16-byte loads), an inclusive scan inside the 16-lane row locates the pick-th set
@@ -1793,8 +1794,17 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     Params &p = l.p;
     p.P = b->pool_size;
     p.T = b->pool_len;
-    p.seq_stride = (int32_t)(b->env_id_total % b->pool_size);
-    p.base_mod = (int32_t)(b->env_id_base % b->pool_size);
+    if (b->pool_mode == BPP_POOL_RING) {   // ring of a bpp_stream: row = (episode mod depth) * num_envs + local bin
+        if (b->pool_size % b->num_envs != 0 || b->pool_size / b->num_envs < 4)
+            return fail(BPP_E_BADARG, "bpp_batch: a ring pool holds depth * num_envs rows, depth >= 4");
+        p.seq_stride = b->num_envs % b->pool_size;
+        p.base_mod = 0;
+    } else if (b->pool_mode == BPP_POOL_STATIC) {
+        p.seq_stride = (int32_t)(b->env_id_total % b->pool_size);
+        p.base_mod = (int32_t)(b->env_id_base % b->pool_size);
+    } else {
+        return fail(BPP_E_BADARG, "bpp_batch: unknown pool_mode");
+    }
     p.pool = (const uint32_t *)b->seq_pool;
     p.hmap = b->hmap;
     p.state = b->state;
@@ -1994,8 +2004,23 @@ int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t 
                  int32_t bound_hi, uint64_t seed0, int32_t threads) {
     if (!pool || !bpp_gen_cut2_args_ok(n, T, W, L, H, bound_lo, bound_hi))
         return fail(BPP_E_BADARG, "bpp_gen_cut2: bad argument (bin must exceed bound_hi on some side and bound_lo on none)");
+    // same generator as the device stream (bpp_stream_gen.inl), one private random.Random(seed0 + k) per row
     const int st = run_rows_threaded(n, threads, [=](int k0, int k1) {
-        return bpp_gen_cut2_range(pool, lengths, k0, k1, T, W, L, H, bound_lo, bound_hi, seed0);
+        std::vector<uint32_t> mt(624);
+        std::vector<CutBox> boxes((size_t)stream_work_entries(W, L, H, bound_lo));
+        const uint32_t term = (uint32_t)W | ((uint32_t)L << 8) | ((uint32_t)H << 16);
+        int over = 0;
+        for (int k = k0; k < k1; ++k) {
+            StridedMT rng{mt.data(), 1, 624};
+            rng.seed(seed0 + (uint64_t)k);
+            StridedWork work{boxes.data(), 1};
+            uint32_t *row = (uint32_t *)pool + (size_t)k * T;
+            const int cnt = cut2_generate(rng, work, W, L, H, bound_lo, bound_hi, row, T - 1);
+            for (int t = cnt < T - 1 ? cnt : T - 1; t < T; ++t) row[t] = term;
+            if (lengths) lengths[k] = cnt;
+            over |= cnt > T - 1;
+        }
+        return over;
     });
     return st ? fail(BPP_E_TOOLARGE, "bpp_gen_cut2: a sequence does not fit in T-1 entries") : 0;
 }
@@ -2066,6 +2091,52 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
         o.sample_seed = seed;
         o.sample_step = step0 + (uint64_t)t + 1;
         rc = bpp_step(b, actions, &o, stream);
+    }
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+int check_stream(const bpp_stream *s) {
+    if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
+    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0)
+        return fail(BPP_E_BADARG, "bpp_stream: need num_envs > 0, depth >= 4, pool_len >= 2");
+    if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi))
+        return fail(BPP_E_BADARG, "bpp_stream: bin / bounds the reference generator cannot cut");
+    if (((uintptr_t)s->ring & 3u) || ((uintptr_t)s->work & 7u)) return fail(BPP_E_BADARG, "bpp_stream: misaligned buffer");
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int bpp_stream_init(const bpp_stream *s, void *stream) {
+    int rc = check_stream(s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stream_init_kernel, dim3((s->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_stream_refill(const bpp_stream *s, void *stream) {
+    int rc = check_stream(s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
+                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
+    if (!b || !s) return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: NULL pointer");
+    if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - 3)
+        return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");
+    int rc = 0;
+    for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every) {
+        const int32_t n = nsteps - done < refill_every ? nsteps - done : refill_every;
+        rc = bpp_rollout_uniform(b, out, actions, seed, step0 + (uint64_t)done, n, stream);
+        if (rc == 0) rc = bpp_stream_refill(s, stream);
     }
     return rc;
 }

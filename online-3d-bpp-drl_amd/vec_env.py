@@ -116,10 +116,15 @@ class BppVecEnv(object):
     fresh_outputs:  allocate new output tensors every step (reference semantics: results of earlier
                     steps stay valid); False = reuse one set of buffers, results are valid until the
                     next step/reset call.
+    stream:         instead of `pool`: dict(bound=(lo, hi), seed=s, depth=D, refill_every=R) -- an endless CUT-2
+                    supply generated on the device (include/bpp_abi.h: bpp_stream).  Every bin owns an exact
+                    random.Random(seed + global bin id); its k-th episode plays the k-th sequence that stream
+                    yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.  A refill
+                    kernel runs every R <= D - 3 lock-steps (default D = 8, R = 5).
     """
 
     def __init__(self, num_envs, container_size=(10, 10, 10), enable_rotation=False, pool=None, device="cuda",
-                 env_id_base=0, env_id_total=None, mask_rule="utils", compute_mask=True, fresh_outputs=False):
+                 env_id_base=0, env_id_total=None, mask_rule="utils", compute_mask=True, fresh_outputs=False, stream=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BppVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -142,26 +147,57 @@ class BppVecEnv(object):
         # bin3D.py:38-41
         self.action_space = Discrete(self.act_len)
         self.observation_space = Box(low=0.0, high=self.H, shape=(self.obs_len,))
-        if pool is None:
-            raise ValueError("an item-sequence pool is required (see sequences.cut2_pool / rs_pool)")
-        self.pool_host = check_pool(pool, self.bin_size)
+        if (pool is None) == (stream is None):
+            raise ValueError("give either an item-sequence pool (sequences.cut2_pool / cut1_pool / rs_pool) or stream=dict(...)")
+        self.pool_host = check_pool(pool, self.bin_size) if pool is not None else None
         self.mask_rule = {"utils": _lib.RULE_UTILS, "space": _lib.RULE_SPACE}[mask_rule]
         self.compute_mask = bool(compute_mask)
         self.fresh_outputs = bool(fresh_outputs)
         self.env_id_base = int(env_id_base)
         self.env_id_total = int(env_id_total) if env_id_total is not None else self.env_id_base + self.E
         dev = self.device
+        self.stream_spec = None
         with torch.cuda.device(dev):
-            self.pool = torch.from_numpy(self.pool_host).to(dev)
+            if stream is None:
+                self.pool = torch.from_numpy(self.pool_host).to(dev)
+                pool_rows, pool_len, pool_mode = self.pool_host.shape[0], self.pool_host.shape[1], _lib.POOL_STATIC
+            else:
+                lo, hi = (int(v) for v in stream.get("bound", (2, 5)))
+                depth = int(stream.get("depth", 8))
+                if depth < 4:
+                    raise ValueError("stream depth must be >= 4")
+                pool_len = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 1))
+                self.refill_every = int(stream.get("refill_every", depth - 3))
+                if not 1 <= self.refill_every <= depth - 3:
+                    raise ValueError("refill_every must be in 1 .. depth - 3")
+                self.pool = torch.zeros((depth * self.E, pool_len, 4), dtype=torch.uint8, device=dev)   # the ring
+                self._mt = torch.zeros((625, self.E), dtype=torch.int32, device=dev)
+                self._work = torch.zeros((self.W * self.L * self.H // lo ** 3 + 8, self.E, 2), dtype=torch.int32, device=dev)
+                self.gen_next = torch.zeros((self.E,), dtype=torch.int32, device=dev)
+                self.stream_overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
+                pool_rows, pool_mode = depth * self.E, _lib.POOL_RING
+                self.stream_spec = dict(bound=(lo, hi), seed=int(stream.get("seed", 0)), depth=depth, pool_len=pool_len,
+                                        refill_every=self.refill_every)
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
             self.state = torch.zeros((self.E, 12), dtype=torch.int32, device=dev)  # bpp_env_state[E], 48 B each
             # episode statistics accumulated inside the step kernel: [slots][return, ratio, length, count]
             self.stats_slots = torch.zeros((_lib.STATS_SLOTS, 4), dtype=torch.float64, device=dev)
         self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
-                                 self.pool_host.shape[0], self.pool_host.shape[1], self.env_id_base, self.env_id_total,
+                                 pool_rows, pool_len, self.env_id_base, self.env_id_total,
                                  self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr(),
-                                 self.stats_slots.data_ptr())
+                                 self.stats_slots.data_ptr(), pool_mode, 0)
         self._batch_ref = ctypes.byref(self._batch)
+        self._stream = None
+        self._since_refill = 0
+        if self.stream_spec is not None:
+            sp = self.stream_spec
+            self._stream = _lib.Stream(self.E, sp["depth"], sp["pool_len"], self.W, self.L, self.H, sp["bound"][0], sp["bound"][1],
+                                       self.env_id_base, sp["seed"], self.pool.data_ptr(), self._mt.data_ptr(),
+                                       self._work.data_ptr(), self.gen_next.data_ptr(), self.state.data_ptr(),
+                                       self.stream_overflow.data_ptr())
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.bpp_stream_init(ctypes.byref(self._stream), self._stream_ptr()))
+            self.refill()
         self._bufs = None
         self._out = None
         self._res = None
@@ -203,8 +239,22 @@ class BppVecEnv(object):
             self._bufs, self._out = self._alloc()
         return self._bufs, self._out
 
-    def _stream(self):
+    def _stream_ptr(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def refill(self):
+        """Streaming supply: cut new sequences for the episodes the bins have consumed (one kernel, no host sync)."""
+        if self._stream is None:
+            raise RuntimeError("refill() needs a streaming env (stream=dict(...))")
+        self._on_device()
+        _lib.check(self.lib.bpp_stream_refill(ctypes.byref(self._stream), self._stream_ptr()))
+        self._since_refill = 0
+
+    def _stepped(self, n=1):
+        if self._stream is not None:
+            self._since_refill += n
+            if self._since_refill >= self.refill_every:
+                self.refill()
 
     def _on_device(self):
         """HIP launches target the calling thread's current device: make sure it is ours (cheap check,
@@ -219,7 +269,10 @@ class BppVecEnv(object):
         bufs, out = self._buffers()
         self._res = StepTensors(**bufs)
         mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
-        _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(out), self._stream()))
+        if self._stream is not None and not self._first_reset:
+            self.refill()              # RESET_ADVANCE moves every bin on by one episode
+        _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(out), self._stream_ptr()))
+        self._stepped()
         self._first_reset = False
         self._tstart = time.time()
         self.location_masks = bufs["mask"]
@@ -252,9 +305,10 @@ class BppVecEnv(object):
                 raise ValueError("sample out tensor must be a contiguous int64 [E] tensor on the env's device")
             out = _lib.StepOut.from_buffer_copy(self._out)
             out.next_action, out.sample_seed, out.sample_step = nxt.data_ptr(), int(seed), int(step)
-        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), self._stream())
+        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), self._stream_ptr())
         if rc:
             _lib.check(rc)
+        self._stepped()
         return self._res
 
     def rollout_uniform(self, seed, step0, nsteps, actions=None):
@@ -269,8 +323,14 @@ class BppVecEnv(object):
         if actions is None:
             actions = torch.empty((self.E,), dtype=torch.int64, device=self.device)
         self._on_device()
+        if self._stream is not None:
+            self.refill()
+            _lib.check(self.lib.bpp_rollout_uniform_stream(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
+                                                           int(step0), int(nsteps), ctypes.byref(self._stream),
+                                                           self.refill_every, self._stream_ptr()))
+            return self._res
         _lib.check(self.lib.bpp_rollout_uniform(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
-                                                int(step0), int(nsteps), self._stream()))
+                                                int(step0), int(nsteps), self._stream_ptr()))
         return self._res
 
     def step_async(self, actions):
@@ -303,7 +363,7 @@ class BppVecEnv(object):
             out = torch.empty((self.E,), dtype=torch.int64, device=self.device)
         self._on_device()
         rc = self.lib.bpp_sample_feasible(m.data_ptr(), out.data_ptr(), self.E, m.shape[1], self.env_id_base, int(seed),
-                                          int(step), self._stream())
+                                          int(step), self._stream_ptr())
         if rc:
             _lib.check(rc)
         return out
@@ -328,6 +388,12 @@ class BppVecEnv(object):
             raise ValueError("src and dst must have the same length")
         self.hmap[dst] = self.hmap[src]
         self.state[dst] = self.state[src]
+        if self._stream is not None:       # the copy continues the source's item stream: ring rows + generator state
+            ring = self.pool.view(self.stream_spec["depth"], self.E, -1)
+            ring[:, dst] = ring[:, src]
+            self._mt[:, dst] = self._mt[:, src]
+            self._work[:, dst] = self._work[:, src]
+            self.gen_next[dst] = self.gen_next[src]
 
     def preview(self, k):
         """The next `k` items of every bin, int32 [E, k, 3] -- `box_creator.preview(k)`

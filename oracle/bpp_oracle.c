@@ -146,13 +146,24 @@ static int check_batch(const bpp_batch *b) {
     if (b->env_id_total < b->env_id_base + b->num_envs) return fail(BPP_E_BADARG, "bpp_batch: env_id_total too small");
     if (b->mask_rule != BPP_RULE_UTILS && b->mask_rule != BPP_RULE_SPACE) return fail(BPP_E_BADARG, "bpp_batch: bad mask_rule");
     if (b->H > 255) return fail(BPP_E_TOOLARGE, "bpp_batch: H > 255");
+    if (b->pool_mode != BPP_POOL_STATIC && b->pool_mode != BPP_POOL_RING) return fail(BPP_E_BADARG, "bpp_batch: unknown pool_mode");
+    if (b->pool_mode == BPP_POOL_RING && (b->pool_size % b->num_envs != 0 || b->pool_size / b->num_envs < 4))
+        return fail(BPP_E_BADARG, "bpp_batch: a ring pool holds depth * num_envs rows, depth >= 4");
     return 0;
+}
+
+/* Pool row episode `episode` of local bin e plays (include/bpp_abi.h: bpp_batch.pool_mode). */
+static int64_t pool_row(const bpp_batch *b, int e, int64_t episode) {
+    if (b->pool_mode == BPP_POOL_RING) {
+        int64_t depth = b->pool_size / b->num_envs;
+        return (episode % depth) * b->num_envs + e;
+    }
+    return (b->env_id_base + e + episode * b->env_id_total) % b->pool_size;
 }
 
 /* BoxCreator.preview(1)[0] (envs/bpp0/binCreator.py:15-18) on the pooled sequence this bin plays. */
 static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item[3]) {
-    int64_t gid = b->env_id_base + e;
-    int64_t seq = (gid + (int64_t)s->episode * b->env_id_total) % b->pool_size;
+    int64_t seq = pool_row(b, e, s->episode);
     int c = s->cursor < b->pool_len ? s->cursor : b->pool_len - 1;
     const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
     item[0] = p[0];
@@ -166,8 +177,8 @@ static uint32_t pool_entry(const bpp_batch *b, int64_t seq, int c) {
     const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
-static void refresh_item_cache(const bpp_batch *b, bpp_env_state *s) {
-    int64_t seq_n = ((int64_t)s->seq + b->env_id_total % b->pool_size) % b->pool_size;
+static void refresh_item_cache(const bpp_batch *b, int e, bpp_env_state *s) {
+    int64_t seq_n = pool_row(b, e, (int64_t)s->episode + 1);
     s->item_cur = pool_entry(b, s->seq, s->cursor);
     s->item_next = pool_entry(b, s->seq, s->cursor + 1);
     s->item_reset = pool_entry(b, seq_n, 0);
@@ -200,7 +211,7 @@ static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
     s->vol_sum = 0;
     s->ep_ret = 0.0;
     s->ep_len = 0;
-    s->seq = (int32_t)((b->env_id_base + e + (int64_t)s->episode * b->env_id_total) % b->pool_size);
+    s->seq = (int32_t)pool_row(b, e, s->episode);
 }
 
 int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream) {
@@ -215,7 +226,7 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
         reset_bin(b, e, s);
         int item[3];
         next_box(b, e, s, item);
-        refresh_item_cache(b, s);
+        refresh_item_cache(b, e, s);
         write_obs_mask(b, e, item, out);
     }
     return 0;
@@ -299,7 +310,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
             reset_bin(b, e, s);
         }
         next_box(b, e, s, item);
-        refresh_item_cache(b, s);
+        refresh_item_cache(b, e, s);
         write_obs_mask(b, e, item, out);
     }
     if (out->next_action) {
@@ -482,4 +493,62 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
         return fail(BPP_E_BADARG, "bpp_gen_rs: bad argument");
     bpp_gen_rs_range(pool, 0, n, T, W, L, H, box_set, n_box, seed0);
     return 0;
+}
+
+/* ---- endless CUT-2 supply (include/bpp_abi.h: bpp_stream), host version: one bpp_mt per bin in `mt` (the buffer is
+ * opaque, 625 words per bin either way), sequences drawn one after the other with include/bpp_gen.inl ---------- */
+static int check_stream(const bpp_stream *s) {
+    if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
+    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0) return fail(BPP_E_BADARG, "bpp_stream: bad size");
+    if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi)) return fail(BPP_E_BADARG, "bpp_stream: bad bounds");
+    return 0;
+}
+
+int bpp_stream_init(const bpp_stream *s, void *stream) {
+    (void)stream;
+    int rc = check_stream(s);
+    if (rc) return rc;
+    bpp_mt *rngs = (bpp_mt *)s->mt;
+    for (int e = 0; e < s->num_envs; ++e) {
+        bpp_mt_seed(&rngs[e], s->seed0 + (uint64_t)(s->env_id_base + e));
+        s->gen_next[e] = 0;
+    }
+    return 0;
+}
+
+int bpp_stream_refill(const bpp_stream *s, void *stream) {
+    (void)stream;
+    int rc = check_stream(s);
+    if (rc) return rc;
+    bpp_mt *rngs = (bpp_mt *)s->mt;
+    const int E = s->num_envs, T = s->pool_len, D = s->depth;
+    for (int e = 0; e < E; ++e) {
+        while (s->gen_next[e] < s->state[e].episode + D) {
+            uint8_t *row = s->ring + ((size_t)(s->gen_next[e] % D) * E + e) * T * 4;
+            for (int t = 0; t < T; ++t) {
+                row[4 * t] = (uint8_t)s->W;
+                row[4 * t + 1] = (uint8_t)s->L;
+                row[4 * t + 2] = (uint8_t)s->H;
+                row[4 * t + 3] = 0;
+            }
+            int n = bpp_cut2_from_stream(&rngs[e], s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
+            if (n > T - 1 && s->overflow) s->overflow[0] += 1;
+            s->gen_next[e] += 1;
+        }
+    }
+    return 0;
+}
+
+int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
+                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
+    if (!b || !s) return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: NULL pointer");
+    if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - 3)
+        return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");
+    int rc = 0;
+    for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every) {
+        int32_t n = nsteps - done < refill_every ? nsteps - done : refill_every;
+        rc = bpp_rollout_uniform(b, out, actions, seed, step0 + (uint64_t)done, n, stream);
+        if (rc == 0) rc = bpp_stream_refill(s, stream);
+    }
+    return rc;
 }

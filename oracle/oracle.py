@@ -27,7 +27,14 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p)]
+                ("stats", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+
+
+class Stream(ctypes.Structure):
+    _fields_ = [("num_envs", ctypes.c_int32), ("depth", ctypes.c_int32), ("pool_len", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("L", ctypes.c_int32), ("H", ctypes.c_int32), ("bound_lo", ctypes.c_int32), ("bound_hi", ctypes.c_int32),
+                ("env_id_base", ctypes.c_int64), ("seed0", ctypes.c_uint64), ("ring", ctypes.c_void_p), ("mt", ctypes.c_void_p),
+                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p)]
 
 
 class StepOut(ctypes.Structure):
@@ -88,6 +95,11 @@ def lib():
                                                                                      ctypes.c_uint64, ctypes.c_int32]
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
+        L.bpp_stream_init.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
+        L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
+        L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
+                                                 ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
+                                                 ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -105,10 +117,18 @@ def _p(a):
 class OracleEnv(object):
     """E bins stepped in lock-step on the host by the C restatement."""
 
-    def __init__(self, pool, size, rotation, num_envs, env_id_base=0, env_id_total=None, mask_rule=RULE_UTILS):
+    def __init__(self, pool, size, rotation, num_envs, env_id_base=0, env_id_total=None, mask_rule=RULE_UTILS, stream=None):
+        """stream=dict(bound=(lo, hi), seed=s, depth=D[, pool_len=T]): endless CUT-2 supply through a ring pool
+        (include/bpp_abi.h: bpp_stream) instead of `pool` (pass pool=None)."""
+        self.W, self.L, self.H = (int(v) for v in size)
+        self.stream = None
+        if stream is not None:
+            lo, hi = (int(v) for v in stream.get("bound", (2, 5)))
+            D = int(stream.get("depth", 8))
+            T = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 1))
+            pool = np.zeros((D * int(num_envs), T, 4), np.uint8)
         self.pool = np.ascontiguousarray(pool, dtype=np.uint8)
         assert self.pool.ndim == 3 and self.pool.shape[2] == 4
-        self.W, self.L, self.H = (int(v) for v in size)
         self.A = self.W * self.L
         self.rotation = int(bool(rotation))
         self.M = self.A * (1 + self.rotation)
@@ -123,27 +143,60 @@ class OracleEnv(object):
         self._b = Batch(self.E, self.W, self.L, self.H, self.rotation, int(mask_rule), self.pool.shape[0],
                         self.pool.shape[1], int(env_id_base),
                         int(env_id_total if env_id_total is not None else env_id_base + self.E),
-                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.stats).value)
+                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.stats).value,
+                        1 if stream is not None else 0, 0)
+        if stream is not None:
+            E = self.E
+            self._mt = np.zeros((625, E), np.uint32)
+            self._work = np.zeros((self.W * self.L * self.H // lo ** 3 + 8, E, 2), np.uint32)
+            self.gen_next = np.zeros(E, np.int32)
+            self.overflow = np.zeros(1, np.int32)
+            self.stream = Stream(E, D, T, self.W, self.L, self.H, lo, hi, int(env_id_base), int(stream.get("seed", 0)),
+                                 _p(self.pool).value, _p(self._mt).value, _p(self._work).value, _p(self.gen_next).value,
+                                 _p(self.state).value, _p(self.overflow).value)
+            self.refill_every = int(stream.get("refill_every", max(1, D - 3)))
+            self._since_refill = 0
+            _check(lib().bpp_stream_init(ctypes.byref(self.stream), None))
+            self.refill()
         self._o = StepOut(*[_p(self.out[k]).value for k in ("obs", "mask", "reward", "done", "counter", "ratio",
                                                               "ep_ret", "ep_len")])
         self._first = True
 
+    def refill(self):
+        _check(lib().bpp_stream_refill(ctypes.byref(self.stream), None))
+        self._since_refill = 0
+
+    def _after_steps(self, n):
+        if self.stream is not None:
+            self._since_refill += n
+            if self._since_refill >= self.refill_every:
+                self.refill()
+
     def reset(self):
+        if self.stream is not None and not self._first:
+            self.refill()                      # a VecEnv.reset() advances every bin by one episode
         _check(lib().bpp_reset(ctypes.byref(self._b), RESET_INIT if self._first else RESET_ADVANCE,
                                ctypes.byref(self._o), None))
         self._first = False
+        self._after_steps(1)
         return self.out["obs"].copy(), self.out["mask"].copy()
 
     def step(self, actions, copy=True):
         a = np.ascontiguousarray(np.asarray(actions).reshape(-1), dtype=np.int64)
         assert a.shape[0] == self.E
         _check(lib().bpp_step(ctypes.byref(self._b), _p(a), ctypes.byref(self._o), None))
+        self._after_steps(1)
         return {k: v.copy() for k, v in self.out.items()} if copy else self.out
 
 
 def rollout_uniform(env, seed, step0, nsteps):
     """nsteps lock-steps of OracleEnv `env` under the uniform-feasible policy; returns env.out (views)."""
     a = np.zeros(env.E, np.int64)
+    if env.stream is not None:
+        env.refill()
+        _check(lib().bpp_rollout_uniform_stream(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
+                                                int(nsteps), ctypes.byref(env.stream), env.refill_every, None))
+        return env.out, a
     _check(lib().bpp_rollout_uniform(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
                                      int(nsteps), None))
     return env.out, a
