@@ -41,6 +41,11 @@ extern "C" {
 
 #define BPP_STATS_SLOTS 256
 
+/* bpp_step action meaning "leave this bin alone" (no reference counterpart: the reference steps its envs one at a
+ * time; lookahead searches step a SUBSET of a batch): state, heightmap and Monitor sums stay as
+ * they are, reward 0, done 0, and the bin's current observation and mask are written again. */
+#define BPP_ACTION_NOOP INT64_MIN
+
 /* bpp_reset modes */
 #define BPP_RESET_INIT    0 /* first reset: episode index 0                                        */
 #define BPP_RESET_ADVANCE 1 /* later VecEnv.reset(): every bin abandons its episode, next sequence */

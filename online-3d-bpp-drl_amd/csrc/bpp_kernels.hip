@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             // bin3D.py:96-105: rotated iff idx > area (strict)
+            const bool noop = act == BPP_ACTION_NOOP;   // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;
             const bool flag = p.rotation && idx > A;
             if (flag) idx -= A;
@@ -333,14 +334,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.n_boxes += ok ? 1 : 0;
             st.vol_sum += ok ? vol : 0;
             st.ep_ret = st.ep_ret + rew;  // bench/monitor.py:58-62 (sum in step order)
-            st.ep_len += 1;
+            st.ep_len += noop ? 0 : 1;
             p.reward[e] = (float)rew;     // acktr/envs.py:192
-            p.done[e] = ok ? 0 : 1;
+            p.done[e] = (ok || noop) ? 0 : 1;
             p.counter[e] = st.n_boxes;    // bin3D.py:111,124
             p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
             p.ep_ret[e] = st.ep_ret;
             p.ep_len[e] = st.ep_len;
-            fin = !ok;
+            fin = !ok && !noop;
             fin_ret = st.ep_ret;
             fin_ratio = (double)st.vol_sum / p.binvol;
             fin_len = st.ep_len;
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
+            } else if (noop) {
+                r.item = it_cur;
             } else {  // shmem_vec_env.py:128-129 auto-reset; bin3D.py:55-59
                 st.episode += 1;
                 st.seq = seq_n;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             const uint32_t sp_f1 = p.pool[(size_t)seq_n * T + min(1, T - 1)];
             const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
+            const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
             const bool flag = ROT && idx > A;
             if (flag) idx -= A;
@@ -863,17 +867,17 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             st.n_boxes += ok ? 1 : 0;
             st.vol_sum += ok ? vol : 0;
             st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
-            st.ep_len += 1;
+            st.ep_len += noop ? 0 : 1;
             const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
             if (active) {
                 p.reward[e] = (float)rew;                              // acktr/envs.py:192
-                p.done[e] = ok ? 0 : 1;
+                p.done[e] = (ok || noop) ? 0 : 1;
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
                 p.ratio[e] = ratio;
                 p.ep_ret[e] = st.ep_ret;
                 p.ep_len[e] = st.ep_len;
             }
-            fin = active && !ok;
+            fin = active && !ok && !noop;
             fin_ret = st.ep_ret;
             fin_ratio = ratio;
             fin_len = st.ep_len;
@@ -884,6 +888,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
+            } else if (noop) {
+                r.item = it_cur;
             } else {                                                   // shmem_vec_env.py:128-129
                 st.episode += 1;
                 st.seq = seq_n;

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             const uint32_t sp_f1 = p.pool[(size_t)seq_n * Tn + min(1, Tn - 1)];
             const uint32_t sp_f2 = p.pool[(size_t)seq_nn * Tn];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
+            const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
             const bool flag = ROT && idx > A;
             if (flag) idx -= A;
@@ -257,12 +258,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             st.n_boxes += ok ? 1 : 0;
             st.vol_sum += ok ? vol : 0;
             st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
-            st.ep_len += 1;
+            st.ep_len += noop ? 0 : 1;
             const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
             out_rew = (float)rew;                                      // acktr/envs.py:192
-            out_ok = ok;
+            out_ok = ok || noop;
             out_boxes = st.n_boxes;                                    // bin3D.py:111,124
-            fin = lead && !ok;
+            fin = lead && !ok && !noop;
             fin_ret = st.ep_ret;
             fin_ratio = ratio;
             fin_len = st.ep_len;
@@ -273,6 +274,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
+            } else if (noop) {
+                r.item = it_cur;
             } else {                                                   // shmem_vec_env.py:128-129
                 st.episode += 1;
                 st.seq = seq_n;

@@ -40,4 +40,31 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
         pool = make_pool(size, getattr(args, "data_type", getattr(args, "item_seq", "cut2")),
                          getattr(args, "box_size_set", None), rot, seed=int(seed), pool_size=pool_size)
     env_kwargs.setdefault("fresh_outputs", True)   # reference semantics: earlier results stay valid
-    return BppVecEnv(int(num_processes), size, enable_rotation=rot, pool=pool, device=device, **env_kwargs)
+    env = BppVecEnv(int(num_processes), size, enable_rotation=rot, pool=pool, device=device, **env_kwargs)
+    env.venv = _vec_normalize_holder()
+    return env
+
+
+class _ObRmsHolder(object):
+    """Stands where the reference has VecNormalize: the training loop only reads / writes `.ob_rms` through
+    utils.get_vec_normalize(envs) (main.py:77,190; acktr/utils.py:96-102); the reference disables both of
+    VecNormalize's filters (acktr/envs.py:112), so there is nothing else to hold."""
+    ob_rms = None
+
+
+def _vec_normalize_holder():
+    """utils.get_vec_normalize walks `.venv` until it finds an instance of the reference's own VecNormalize class.
+    When that class is loaded in this process (the reference's training loop is what is running) the holder is an
+    instance of it, created without running its constructor, so `setattr(utils.get_vec_normalize(envs), 'ob_rms', ...)`
+    of the --pretrain path and the `getattr(..., 'ob_rms', None)` of the save path work on the unmodified main.py."""
+    import sys
+    mod = sys.modules.get("acktr.envs")
+    cls = getattr(mod, "VecNormalize", None) if mod is not None else None
+    if cls is not None:
+        try:
+            holder = cls.__new__(cls)
+            holder.ob_rms = None
+            return holder
+        except Exception:  # noqa: BLE001 -- any oddity of a foreign class: fall back to the plain holder
+            pass
+    return _ObRmsHolder()

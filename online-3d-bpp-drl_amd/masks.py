@@ -56,6 +56,32 @@ def batched_mask_from_hmap(hmap, items, container_size, enable_rotation=False, r
     return out
 
 
+def batched_window_masks(hmap, items, window_size, stride=10, enable_rotation=False, rule="utils"):
+    """Sliding-window masks of a larger pallet, batched (multi_bin/multi_bin.py:7-17 `slipingWindow` + :28-45: every
+    window of `window_size` = (w, l, H) over the big heightmap becomes its own bin and gets
+    get_possible_position(window_obs, window_size)).  hmap: int [E, Wb, Lb]; items: int [E, 3].
+    Returns (masks float32 [E, n_windows, M], offsets int64 [n_windows, 2]) with windows in the reference's order
+    (dx outer, dy inner, both stepping by `stride`)."""
+    w, l, H = (int(v) for v in window_size)
+    dev = hmap.device if torch.is_tensor(hmap) and hmap.device.type == "cuda" else _dev()
+    h = torch.as_tensor(hmap).to(device=dev, dtype=torch.int32)
+    if h.dim() != 3:
+        raise ValueError("hmap must be [E, Wb, Lb]")
+    E, Wb, Lb = h.shape
+    it = torch.as_tensor(items).reshape(-1, 3).to(device=dev, dtype=torch.int32)
+    if it.shape[0] != E:
+        raise ValueError("hmap and items disagree on the number of bins")
+    xs = list(range(0, Wb - w + 1, int(stride)))
+    ys = list(range(0, Lb - l + 1, int(stride)))
+    if not xs or not ys:
+        raise ValueError("window larger than the pallet")
+    wins = torch.stack([h[:, dx:dx + w, dy:dy + l].reshape(E, w * l) for dx in xs for dy in ys], dim=1)   # [E, n, w*l]
+    n = wins.shape[1]
+    masks = batched_mask_from_hmap(wins.reshape(E * n, w * l), it.repeat_interleave(n, dim=0), (w, l, H), enable_rotation, rule)
+    offsets = torch.tensor([(dx, dy) for dx in xs for dy in ys], dtype=torch.int64)
+    return masks.view(E, n, -1), offsets
+
+
 def get_possible_position(observation, container_size):
     """Same signature and return type as acktr.utils.get_possible_position (acktr/utils.py:37-62):
     one observation row -> python list of W*L ints."""

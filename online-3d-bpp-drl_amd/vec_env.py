@@ -29,6 +29,17 @@ class StepTensors(object):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
+    @property
+    def masks(self):
+        """float32 [E,1]: 0 where the episode just ended, else 1 -- `masks` of main.py:172 (rollouts.insert)."""
+        return 1.0 - self.done.to(torch.float32).reshape(-1, 1)
+
+    @property
+    def bad_masks(self):
+        """float32 [E,1] of ones: main.py:173 sets 0 only for 'bad_transition' infos (time-limit truncations), which this
+        environment -- like the reference's PackingGame -- never produces."""
+        return torch.ones((self.done.numel(), 1), dtype=torch.float32, device=self.done.device)
+
     def host_scalars(self):
         """reward, done, counter, ratio, ep_ret, ep_len as numpy arrays with ONE device->host copy."""
         E = self.done.numel()
@@ -353,6 +364,16 @@ class BppVecEnv(object):
     def close(self):
         self.closed = True
 
+    def render(self, mode="human"):
+        raise NotImplementedError("BppVecEnv has no renderer (the reference's PackingGame.render is a no-op too)")
+
+    def get_images(self):
+        raise NotImplementedError("BppVecEnv has no renderer")
+
+    @property
+    def unwrapped(self):
+        return self
+
     # ------------------------------------------------------------------ extras
     def sample_feasible(self, seed, step, mask=None, out=None):
         """Uniform random feasible action per bin (bench/test action source), int64 [E] on the device."""
@@ -377,6 +398,44 @@ class BppVecEnv(object):
         return acc
 
     # ------------------------------------------------------------------ lookahead support
+    NOOP = -2 ** 63      # BPP_ACTION_NOOP: this bin is not stepped (state untouched, reward 0, done 0, obs/mask re-emitted)
+
+    def step_subset(self, ids, actions, sample=None):
+        """Step only bins `ids` with `actions`; every other bin is left alone (BPP_ACTION_NOOP).  The lookahead
+        searches of the reference step one deep-copied env at a time (acktr/reorder.py:245-262, MCTS/node.py:92-137);
+        here the copies are bins of the same batch and one launch steps the chosen ones.  Returns StepTensors for
+        the whole batch (untouched bins: reward 0, done 0, their current observation and mask)."""
+        ids = torch.as_tensor(ids, dtype=torch.int64, device=self.device).reshape(-1)
+        a = torch.as_tensor(actions, device=self.device).reshape(-1).to(torch.int64)
+        if ids.numel() != a.numel():
+            raise ValueError("ids and actions must have the same length")
+        full = torch.full((self.E,), self.NOOP, dtype=torch.int64, device=self.device)
+        full[ids] = a
+        return self.step_tensors(full, sample=sample)
+
+    def observe(self):
+        """Re-emit every bin's current observation and mask without stepping (all bins BPP_ACTION_NOOP): what a
+        search calls after editing bins (copy_bins / set_current_items)."""
+        return self.step_tensors(torch.full((self.E,), self.NOOP, dtype=torch.int64, device=self.device))
+
+    def clone_into(self, src, dst, refresh=True):
+        """`copy.deepcopy(env)` of the reference's searches, batched: bins `dst` become exact copies of bins `src`
+        (heightmap, counters, Monitor sums, sequence position -- and the item stream in streaming mode); with
+        refresh=True the observations and masks of ALL bins are re-emitted so the copies can be read / sampled from
+        right away."""
+        self.copy_bins(src, dst)
+        return self.observe() if refresh else None
+
+    def set_current_items(self, ids, items):
+        """Overwrite the item bins `ids` are about to place (int [n,3]); the reorder search plays the previewed items
+        in a different order (acktr/reorder.py:181-215).  Only the current item changes; the sequence continues as
+        before afterwards.  Call observe() to see the new observation / mask."""
+        ids = torch.as_tensor(ids, dtype=torch.int64, device=self.device).reshape(-1)
+        it = torch.as_tensor(items, device=self.device).reshape(-1, 3).to(torch.int32)
+        if it.shape[0] != ids.numel() or bool((it < 1).any()) or bool((it > 255).any()):
+            raise ValueError("items must be [n,3] with sides in 1..255")
+        self.state[ids, 8] = it[:, 0] | (it[:, 1] << 8) | (it[:, 2] << 16)     # bpp_env_state.item_cur
+
     def copy_bins(self, src, dst):
         """Overwrite bins `dst` with the complete state of bins `src` (heightmap + scalar record): the
         device-side replacement of `copy.deepcopy(env)` in the reference's lookahead searches

@@ -161,9 +161,17 @@ static int64_t pool_row(const bpp_batch *b, int e, int64_t episode) {
     return (b->env_id_base + e + episode * b->env_id_total) % b->pool_size;
 }
 
+/* Row of the episode after the one in row `seq` (the record's `seq` field is what a copied bin carries along, so a
+ * copy keeps playing its source's sequences: copy.deepcopy(env) semantics, acktr/reorder.py:247). */
+static int64_t next_row(const bpp_batch *b, int64_t seq) {
+    int64_t stride = b->pool_mode == BPP_POOL_RING ? b->num_envs : b->env_id_total % b->pool_size;
+    return (seq + stride) % b->pool_size;
+}
+
 /* BoxCreator.preview(1)[0] (envs/bpp0/binCreator.py:15-18) on the pooled sequence this bin plays. */
 static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item[3]) {
-    int64_t seq = pool_row(b, e, s->episode);
+    (void)e;
+    int64_t seq = s->seq;
     int c = s->cursor < b->pool_len ? s->cursor : b->pool_len - 1;
     const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
     item[0] = p[0];
@@ -178,7 +186,8 @@ static uint32_t pool_entry(const bpp_batch *b, int64_t seq, int c) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 static void refresh_item_cache(const bpp_batch *b, int e, bpp_env_state *s) {
-    int64_t seq_n = pool_row(b, e, (int64_t)s->episode + 1);
+    (void)e;
+    int64_t seq_n = next_row(b, s->seq);
     s->item_cur = pool_entry(b, s->seq, s->cursor);
     s->item_next = pool_entry(b, s->seq, s->cursor + 1);
     s->item_reset = pool_entry(b, seq_n, 0);
@@ -203,7 +212,7 @@ static void write_obs_mask(const bpp_batch *b, int e, const int item[3], const b
 }
 
 /* PackingGame.reset (bin3D.py:55-59) + Monitor.reset_state (bench/monitor.py:45-49). */
-static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
+static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s, int first) {
     int A = b->W * b->L;
     memset(b->hmap + (size_t)e * A, 0, (size_t)A); /* space.py:22 */
     s->cursor = 0;
@@ -211,7 +220,7 @@ static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s) {
     s->vol_sum = 0;
     s->ep_ret = 0.0;
     s->ep_len = 0;
-    s->seq = (int32_t)pool_row(b, e, s->episode);
+    s->seq = (int32_t)(first ? pool_row(b, e, 0) : next_row(b, s->seq));
 }
 
 int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *stream) {
@@ -223,7 +232,7 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
     for (int e = 0; e < b->num_envs; ++e) {
         bpp_env_state *s = b->state + e;
         s->episode = mode == BPP_RESET_INIT ? 0 : s->episode + 1;
-        reset_bin(b, e, s);
+        reset_bin(b, e, s, mode == BPP_RESET_INIT);
         int item[3];
         next_box(b, e, s, item);
         refresh_item_cache(b, e, s);
@@ -247,6 +256,16 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         for (int k = 0; k < A; ++k) plain[k] = bytes[k];
         int item[3];
         next_box(b, e, s, item);
+        if (actions[e] == BPP_ACTION_NOOP) {            /* include/bpp_abi.h: the bin is left alone */
+            out->counter[e] = s->n_boxes;
+            out->ratio[e] = (double)s->vol_sum / ((double)W * (double)L * (double)H);
+            out->ep_ret[e] = s->ep_ret;
+            out->ep_len[e] = s->ep_len;
+            out->reward[e] = 0.0f;
+            out->done[e] = 0;
+            write_obs_mask(b, e, item, out);
+            continue;
+        }
         /* bin3D.py:96-105 */
         int64_t idx = actions[e];
         int flag = 0;
@@ -307,7 +326,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         }
         if (done) {                                     /* shmem_vec_env.py:128-129 */
             s->episode += 1;
-            reset_bin(b, e, s);
+            reset_bin(b, e, s, 0);
         }
         next_box(b, e, s, item);
         refresh_item_cache(b, e, s);

@@ -75,3 +75,40 @@ def test_episode_stats_all_reduce_is_noop_without_process_group():
     s = bpp_amd.EpisodeStats("cpu")
     s.acc += torch.tensor([4.0, 2.0, 8.0, 2.0], dtype=torch.float64)
     assert s.all_reduce().summary() == {"episodes": 2, "mean_return": 2.0, "mean_ratio": 1.0, "mean_length": 4.0}
+
+
+def _gpu_worker(rank, world, port, pool, out_dir):
+    """Same as _worker, but every rank steps the PRODUCT (both ranks share GPU 0 on a 1-GPU box; gloo collective)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = bpp_amd.shard_range(TOTAL, rank, world)
+    env = bpp_amd.BppVecEnv(hi - lo, SIZE, enable_rotation=True, pool=pool, device="cuda:0", env_id_base=lo, env_id_total=TOTAL)
+    env.reset()
+    obs = []
+    for t in range(STEPS):
+        a = env.sample_feasible(seed=SEED, step=t)
+        obs.append(env.step_tensors(a).obs.cpu().numpy().copy())
+    stats = bpp_amd.EpisodeStats("cuda:0").collect(env)
+    acc = stats.acc.cpu()
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM)        # gloo moves host tensors; on a multi-GPU node this is RCCL on device
+    np.savez(os.path.join(out_dir, "grank%d.npz" % rank), obs=np.stack(obs), acc=acc.numpy(), lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_of_the_product_equal_one_global_run(tmp_path):
+    """The N > 1 path with the HIP kernels doing the stepping: two ranks (sharing the box's GPU) each own a shard of
+    global bin ids; concatenated they equal the oracle's single global run, and the all-reduced statistics agree."""
+    pool = bpp_amd.sequences.cut2_pool(SIZE, 23, seed=2)
+    world = 2
+    mp.spawn(_gpu_worker, args=(world, _free_port(), pool, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "grank%d.npz" % r)) for r in range(world)]
+    g_obs, g_acc = _rollout(pool, 0, TOTAL, TOTAL)
+    np.testing.assert_array_equal(np.concatenate([p["obs"] for p in parts], axis=1), g_obs)
+    for p in parts:
+        np.testing.assert_array_equal(p["acc"][2:], g_acc[2:])
+        np.testing.assert_allclose(p["acc"][:2], g_acc[:2], rtol=1e-12)

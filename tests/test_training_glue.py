@@ -1,0 +1,68 @@
+"""the tensors the environment hands the ACKTR loop go straight into the REFERENCE's own
+RolloutStorage.insert / compute_returns and one ACKTR update (acktr/storage.py:52-111, acktr/algo/acktr_pipeline.py:38-),
+written like main.py:148-183.  Build container only (needs /root/reference); the environment side is the product's
+StepTensors fed from the emulated product kernels (no GPU here), so shapes, dtypes, `masks` / `bad_masks` and the
+`get_vec_normalize` holder are what is under test -- the numbers themselves are covered by the parity suites."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import bpp_amd
+from oracle import ref_shims
+
+pytestmark = pytest.mark.skipif(not ref_shims.available(), reason="reference tree not present")
+
+
+def test_step_tensors_feed_the_reference_rollout_storage_and_acktr_update(emu):
+    ref_shims.install()
+    from acktr import algo, utils
+    from acktr.envs import VecNormalize          # noqa: F401  (loaded so that the holder can be an instance of it)
+    from acktr.model import Policy
+    from acktr.storage import RolloutStorage
+    from bpp_amd.factory import _vec_normalize_holder
+    from bpp_amd.vec_env import StepTensors
+
+    size, E, num_steps, rot = (10, 10, 10), 8, 5, False
+    args = types.SimpleNamespace(channel=4, container_size=size, pallet_size=10, enable_rotation=rot, num_processes=E,
+                                 num_steps=num_steps)
+    obs_space, act_space = bpp_amd.Box(0.0, 10, (400,)), bpp_amd.Discrete(100)
+    torch.manual_seed(0)
+    actor_critic = Policy(obs_space.shape, act_space, base_kwargs={"recurrent": False, "hidden_size": 256, "args": args})
+    # acktr=False: the same update() with RMSprop instead of K-FAC (whose eigendecomposition does not converge on an
+    # 8-env, 5-step CPU batch -- a property of the reference's optimiser, not of the tensors under test)
+    agent = algo.ACKTR(actor_critic, 0.5, 0.01, 1.0, lr=7e-4, eps=1e-5, alpha=0.99, max_grad_norm=0.5, acktr=False, args=args)
+    rollouts = RolloutStorage(num_steps, E, obs_space.shape, act_space, actor_critic.recurrent_hidden_state_size,
+                              can_give_up=False, enable_rotation=rot, pallet_size=10)
+    env = emu.EmuEnv(bpp_amd.sequences.cut2_pool(size, 8, seed=0), size, rot, E)
+    obs, mask = env.reset()
+    rollouts.obs[0].copy_(torch.from_numpy(obs))
+    rollouts.location_masks[0].copy_(torch.from_numpy(mask))
+    location_masks = torch.from_numpy(mask)
+    for step in range(num_steps):                                              # main.py:150-174
+        with torch.no_grad():
+            value, action, action_log_prob, rnn = actor_critic.act(rollouts.obs[step], rollouts.recurrent_hidden_states[step],
+                                                                   rollouts.masks[step], location_masks)
+        o = env.step(action.numpy()[:, 0])
+        res = StepTensors(obs=torch.from_numpy(o["obs"]), mask=torch.from_numpy(o["mask"]),
+                          reward=torch.from_numpy(o["reward"]).unsqueeze(1), done=torch.from_numpy(o["done"]),
+                          counter=torch.from_numpy(o["counter"]), ratio=torch.from_numpy(o["ratio"]),
+                          ep_ret=torch.from_numpy(o["ep_ret"]), ep_len=torch.from_numpy(o["ep_len"]))
+        assert res.masks.dtype == torch.float32 and tuple(res.masks.shape) == (E, 1)
+        assert torch.equal(res.masks[:, 0], torch.tensor([0.0 if d else 1.0 for d in o["done"]]))   # main.py:172
+        assert torch.equal(res.bad_masks, torch.ones(E, 1))                                           # main.py:173
+        location_masks = res.mask
+        rollouts.insert(res.obs, rnn, action, action_log_prob, value, res.reward, res.masks, res.bad_masks, location_masks)
+    with torch.no_grad():
+        next_value = actor_critic.get_value(rollouts.obs[-1], rollouts.recurrent_hidden_states[-1], rollouts.masks[-1]).detach()
+    rollouts.compute_returns(next_value, False, 1.0, 0.95, False)
+    out = agent.update(rollouts)                                                # value, action, entropy, prob, graph losses
+    assert len(out) == 5 and all(np.isfinite(float(v)) for v in out)
+    rollouts.after_update()
+    # --pretrain / save paths of the unmodified main.py (:77, :190)
+    envs = types.SimpleNamespace(venv=_vec_normalize_holder())
+    holder = utils.get_vec_normalize(envs)
+    assert holder is not None and getattr(holder, "ob_rms", "missing") is None
+    setattr(utils.get_vec_normalize(envs), "ob_rms", "restored")
+    assert getattr(utils.get_vec_normalize(envs), "ob_rms", None) == "restored"
