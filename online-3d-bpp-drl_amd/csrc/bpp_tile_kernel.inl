@@ -33,18 +33,20 @@ constexpr CandMagicTable make_cand_magic() {
 }
 __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
-// Integer thresholds of the ratio tests per window area: t95 | t85 << 16, t = floor(k*area/20) + 1.
-struct ThresholdTable {
-    uint32_t v[kMaxArea + 1];
-};
-constexpr ThresholdTable make_thresholds() {
-    ThresholdTable t{};
-    for (uint32_t a = 0; a <= (uint32_t)kMaxArea; ++a) t.v[a] = (19u * a / 20u + 1u) | ((17u * a / 20u + 1u) << 16);
-    return t;
-}
-__constant__ const ThresholdTable kThresholds = make_thresholds();
-
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
+
+// Constants of one (bin, orientation) of the item on display, computed lane-parallel for all the wave's bins at once
+// (one lane per slot) and read back wave-uniformly by the candidate loop: two LDS reads and eight readfirstlane per
+// slot instead of ~100 scalar instructions per bin.
+struct __attribute__((aligned(16))) SlotRec {
+    uint32_t w[8];
+    // w0: index-decode multiplier ceil(2^22 / nj) (23 bits) | nj << 24
+    // w1: nv (candidates, 11 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
+    // w2: x * PW entries (prefix-image row offset) | y << 16
+    // w3: (x - 1) * L (corner offset) | (y - 1) << 16
+    // w4: t95 | t85 << 16          w5: t50 | x << 16 | y << 24
+    // w6: hash32(seed, global bin id, step) of the fused draw      w7: unused
+};
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
@@ -58,7 +60,8 @@ struct TileGeo {
     static constexpr int NPASS = (A + kWave - 1) / kWave;  // candidate passes per orientation (at most A candidates)
     static constexpr int OFF_MK = round16(NBW * A);                              // after the NBW byte tiles
     static constexpr int OFF_REC = round16(OFF_MK + EPW * M);                    // mask bytes of the current group
-    static constexpr int OFF_BAL = OFF_REC + NBW * (int)sizeof(BinRec);          // ballots of the candidate passes
+    static constexpr int OFF_SLOT = OFF_REC + NBW * (int)sizeof(BinRec);         // per (bin, orientation) constants
+    static constexpr int OFF_BAL = OFF_SLOT + EPW * 2 * (int)sizeof(SlotRec);    // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
     static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;                    // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     uint8_t *mk = wb + T::OFF_MK;
     uint32_t *mk32 = (uint32_t *)mk;
     BinRec *recw = (BinRec *)(wb + T::OFF_REC);        // [NBW]
+    SlotRec *slots = (SlotRec *)(wb + T::OFF_SLOT);    // [EPW][2]
     uint64_t *balm = (uint64_t *)(wb + T::OFF_BAL);
     Ent<K> *P = (Ent<K> *)(wb + T::OFF_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;        // heights above H all behave like H+1 (never feasible)
@@ -382,6 +386,36 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         myrec.flags = 0;
         myrec.any = 0;
         if (mine) myrec = rec[el];
+        const bool draw = MODE == kStep && p.next_action != nullptr;
+        // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once;
+        // computed here so that the table load overlaps the placement / store / prefix phases, written to LDS before
+        // the candidate loop
+        SlotRec slot;
+        if (mine && sl < (ROT ? 2 : 1)) {
+            const uint32_t item = myrec.item;
+            const int rot = sl;
+            const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+            const int x = rot ? iy : ix, y = rot ? ix : iy;
+            const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
+            const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
+            const uint32_t area = (uint32_t)(x * y);
+            // floor(k * area / 20) + 1: n / 20 == n * 0xCCCD >> 20 for n < 2^16, here n <= 19 * 1024
+            const uint32_t t95 = ((19u * area * 0xCCCDu) >> 20) + 1u, t85 = ((17u * area * 0xCCCDu) >> 20) + 1u, t50 = (area >> 1) + 1u;
+            const uint32_t hz1 = (uint32_t)max(p.H - z + 1, 0);
+            const bool big = x > kTileX || y > kTileY;
+            // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
+            const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) && (myrec.flags & 2u) != 0u;
+            const bool square = ROT && rot == 1 && x == y && valid;
+            slot.w[0] = kCandMagic.v[nj] | ((uint32_t)nj << 24);
+            slot.w[1] = (uint32_t)nv | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) |
+                     ((uint32_t)square << 31);
+            slot.w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
+            slot.w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
+            slot.w[4] = t95 | (t85 << 16);
+            slot.w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+            slot.w[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
+            slot.w[7] = 0u;
+        }
 
         if (MODE == kStep) {
             // ---- phase 2b: apply the placement (space.py:36-46: window := max_h + z), rows over the bin's lanes;
@@ -488,41 +522,45 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
         }
         wave_sync();
-        const bool draw = MODE == kStep && p.next_action != nullptr;
+        if (mine && sl < (ROT ? 2 : 1)) slots[el * 2 + sl] = slot;   // computed right after the bin records were read
+        wave_sync();
         for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
             const Ent<K> *Pe = P + b * PN;
             const uint8_t *he = hm + b * A;
             uint8_t *me = mk + b * M;
-            const uint32_t item = __builtin_amdgcn_readfirstlane(rec[b].item);
-            // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
-            const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
-                               (__builtin_amdgcn_readfirstlane(rec[b].flags) & 2u) != 0u;
             uint64_t balr[2][BAL_REGS ? NPASS : 1];   // ballots of the passes (scalar registers after unrolling)
             uint32_t dec_od[2], dec_nj[2];            // per-orientation index decode, kept for the draw
+            uint32_t hsh = 0;
             int tot = 0;                              // feasible candidates so far (both orientations)
-    #pragma unroll
+#pragma unroll
             for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
-                // per-orientation constants on the scalar unit: the item is wave-uniform
-                const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-                const int x = rot ? iy : ix, y = rot ? ix : iy;
-                const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
-                const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
-                const uint32_t od = kCandMagic.v[nj];
+                // the slot's constants, wave-uniform: two LDS reads, then scalar registers
+                const uint4 qa = *(const uint4 *)&slots[b * 2 + rot].w[0], qb = *(const uint4 *)&slots[b * 2 + rot].w[4];
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.y);
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.w);
+                const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.x), w5 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.y);
+                if (rot == 0) hsh = (uint32_t)__builtin_amdgcn_readfirstlane(qb.z);
+                const uint32_t od = w0 & 0xffffffu;
+                const int nj = (int)(w0 >> 24), nv = (int)(w1 & 0xffffu), hz1 = (int)((w1 >> 16) & 0x1ffu);
+                const bool valid = (w1 >> 28) & 1u, big = (w1 >> 29) & 1u, fresh = (w1 >> 30) & 1u, square = (w1 >> 31) & 1u;
+                const int xPW = (int)(w2 & 0xffffu), y = (int)(w2 >> 16), x = (int)((w5 >> 16) & 255u);
+                const int o10 = (int)(w3 & 0xffffu), o01 = (int)(w3 >> 16);
+                const int t95 = (int)(w4 & 0xffffu), t85 = (int)(w4 >> 16), t50 = (int)(w5 & 0xffffu);
                 dec_od[rot] = od;
                 dec_nj[rot] = (uint32_t)nj;
-    #pragma unroll
+#pragma unroll
                 for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[rot][ps] = 0ull;
                 if (!BAL_REGS) {
                     for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + rot) * NPASS + ps] = 0ull;
                     wave_sync();
                 }
-                if (ROT && rot == 1 && x == y && valid) {
+                if (ROT && rot == 1 && square) {
                     // square footprint: the turned item's mask (utils.py:81-89) equals the first half
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < (A4 + kWave - 1) / kWave; ++k)
                         if (lane + kWave * k < A4) mk32[b * M4 + A4 + lane + kWave * k] = mk32[b * M4 + lane + kWave * k];
                     if (BAL_REGS) {
-    #pragma unroll
+#pragma unroll
                         for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[1][ps] = balr[0][ps];
                     } else {
                         wave_sync();
@@ -532,12 +570,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     continue;
                 }
                 if (!valid) continue;                                       // item does not fit at all
-                const int area = x * y;
-                const uint32_t thr2 = kThresholds.v[area];
-                const int t95 = thr2 & 0xffffu, t85 = thr2 >> 16, t50 = (area >> 1) + 1;
-                const int hz1 = max(p.H - z + 1, 0);
-                const bool big = x > kTileX || y > kTileY;
-                const int o10 = (x - 1) * L, o01 = y - 1;
                 // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
                 auto run = [&](auto big_c, auto empty_c) {
                     constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
@@ -554,7 +586,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                 const Ent<K> *Pb = Pe + i * PW + j;
                                 int mh, ma;
                                 if (!BIG) {
-                                    const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
+                                    const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[xPW], d = Pb[xPW + y];
                                     Ent<K> h;
     #pragma unroll
                                     for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
@@ -601,7 +633,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
             if (draw) {
                 const int e = e0 + b;
-                const uint32_t hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e));
                 if (tot == 0) {
                     if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
                 } else {

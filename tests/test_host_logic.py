@@ -109,3 +109,12 @@ def test_native_cut2_generator_equals_python_generator(size, bound, seed):
     assert np.array_equal(pool, a) and lengths.max() == a.shape[1] - 1
     with pytest.raises(ValueError):
         sequences.cut2_pool(size, 4, seed=seed, bound=bound, T=5)
+
+
+def test_threshold_magic_division_is_exact():
+    """bpp_tile_kernel derives floor(k * area / 20) as (k * area * 0xCCCD) >> 20 in 32-bit arithmetic (k = 17, 19;
+    area <= 1024, the largest window a supported bin admits): exact and overflow-free."""
+    for area in range(0, 1025):
+        for k in (17, 19):
+            n = k * area
+            assert n * 0xCCCD < 2 ** 32 and (n * 0xCCCD) >> 20 == n // 20
