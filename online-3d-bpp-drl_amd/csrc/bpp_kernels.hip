@@ -1883,7 +1883,8 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
     if (l.tile >= 0) {   // step kernel shape (TileGeo<...>::LDS_BLOCK restated for runtime arguments)
         const TileGeoEntry &g = kTileGeo[l.tile];
         const int A = W * L, M = A * (1 + rotation), npass = (A + kWave - 1) / kWave, nbw = g.epw * l.nit;
-        const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M), off_bal = off_rec + nbw * (int)sizeof(BinRec);
+        const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M), off_slot = off_rec + nbw * (int)sizeof(BinRec);
+        const int off_bal = off_slot + (g.epw > 1 ? g.epw * 2 * (int)sizeof(SlotRec) : 0);
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
         lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K);
         out[2] = nbw;

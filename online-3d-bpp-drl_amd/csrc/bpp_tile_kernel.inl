@@ -50,6 +50,29 @@ struct __attribute__((aligned(16))) SlotRec {
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
+// The six words of a SlotRec that the candidate loop consumes, from the item on display (same code for the
+// lane-parallel and the scalar-unit evaluation).
+template <int W, int L>
+__device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[6]) {
+    constexpr int PW = L + 1;
+    const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+    const int x = rot ? iy : ix, y = rot ? ix : iy;
+    const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
+    const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;                     // utils.py:54-55 loop ranges
+    const uint32_t area = valid ? (uint32_t)(x * y) : 0u;
+    // floor(k * area / 20) + 1: n / 20 == n * 0xCCCD >> 20 for n < 2^16, here n <= 19 * 1024
+    const uint32_t t95 = ((19u * area * 0xCCCDu) >> 20) + 1u, t85 = ((17u * area * 0xCCCDu) >> 20) + 1u, t50 = (area >> 1) + 1u;
+    const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
+    const bool big = x > kTileX || y > kTileY;
+    const bool square = rot_kernel && rot == 1 && x == y && valid;
+    w[0] = kCandMagic.v[nj] | ((uint32_t)nj << 24);
+    w[1] = (uint32_t)nv | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) | ((uint32_t)square << 31);
+    w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
+    w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
+    w[4] = t95 | (t85 << 16);
+    w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+}
+
 template <int W, int L, int K, bool ROT, int EPW, int NIT>
 struct TileGeo {
     static constexpr int A = W * L, A4 = A / 4, M = ROT ? 2 * A : A, M4 = M / 4, PW = L + 1, PN = (W + 1) * (L + 1);
@@ -61,7 +84,9 @@ struct TileGeo {
     static constexpr int OFF_MK = round16(NBW * A);                              // after the NBW byte tiles
     static constexpr int OFF_REC = round16(OFF_MK + EPW * M);                    // mask bytes of the current group
     static constexpr int OFF_SLOT = OFF_REC + NBW * (int)sizeof(BinRec);         // per (bin, orientation) constants
-    static constexpr int OFF_BAL = OFF_SLOT + EPW * 2 * (int)sizeof(SlotRec);    // ballots of the candidate passes
+    // (LDS is handed out in 1280-byte granules on gfx950: the 20x20, K = 2 workgroup must stay <= 32 000 bytes for five
+    // workgroups per CU -- the slot records are therefore only used, and only allocated, when a wave owns several bins)
+    static constexpr int OFF_BAL = OFF_SLOT + (EPW > 1 ? EPW * 2 * (int)sizeof(SlotRec) : 0);   // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
     static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;                    // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
@@ -387,32 +412,11 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         myrec.any = 0;
         if (mine) myrec = rec[el];
         const bool draw = MODE == kStep && p.next_action != nullptr;
-        // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once;
-        // computed here so that the table load overlaps the placement / store / prefix phases, written to LDS before
-        // the candidate loop
+        // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once
         SlotRec slot;
-        if (mine && sl < (ROT ? 2 : 1)) {
-            const uint32_t item = myrec.item;
-            const int rot = sl;
-            const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-            const int x = rot ? iy : ix, y = rot ? ix : iy;
-            const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
-            const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;   // utils.py:54-55 loop ranges
-            const uint32_t area = (uint32_t)(x * y);
-            // floor(k * area / 20) + 1: n / 20 == n * 0xCCCD >> 20 for n < 2^16, here n <= 19 * 1024
-            const uint32_t t95 = ((19u * area * 0xCCCDu) >> 20) + 1u, t85 = ((17u * area * 0xCCCDu) >> 20) + 1u, t50 = (area >> 1) + 1u;
-            const uint32_t hz1 = (uint32_t)max(p.H - z + 1, 0);
-            const bool big = x > kTileX || y > kTileY;
-            // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
-            const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) && (myrec.flags & 2u) != 0u;
-            const bool square = ROT && rot == 1 && x == y && valid;
-            slot.w[0] = kCandMagic.v[nj] | ((uint32_t)nj << 24);
-            slot.w[1] = (uint32_t)nv | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) |
-                     ((uint32_t)square << 31);
-            slot.w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
-            slot.w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
-            slot.w[4] = t95 | (t85 << 16);
-            slot.w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+        constexpr bool kResets = MODE == kStep || MODE == kResetInit || MODE == kResetAdvance;   // a bin that was just reset
+        if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) {           // shows an empty map: its mask is the in-range rectangle
+            make_slot_words<W, L>(myrec.item, sl, kResets && (myrec.flags & 2u) != 0u, ROT, p.H, slot.w);
             slot.w[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
             slot.w[7] = 0u;
         }
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
         }
         wave_sync();
-        if (mine && sl < (ROT ? 2 : 1)) slots[el * 2 + sl] = slot;   // computed right after the bin records were read
+        if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) slots[el * 2 + sl] = slot;   // computed right after the bin records were read
         wave_sync();
         for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
             const Ent<K> *Pe = P + b * PN;
@@ -534,12 +538,23 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             int tot = 0;                              // feasible candidates so far (both orientations)
 #pragma unroll
             for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
-                // the slot's constants, wave-uniform: two LDS reads, then scalar registers
-                const uint4 qa = *(const uint4 *)&slots[b * 2 + rot].w[0], qb = *(const uint4 *)&slots[b * 2 + rot].w[4];
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.y);
-                const uint32_t w2 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.w);
-                const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.x), w5 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.y);
-                if (rot == 0) hsh = (uint32_t)__builtin_amdgcn_readfirstlane(qb.z);
+                // the slot's constants, wave-uniform: two LDS reads, then scalar registers -- or, when the wave owns a
+                // single bin, straight from the item on the scalar unit
+                uint32_t w0, w1, w2, w3, w4, w5;
+                if constexpr (EPW > 1) {
+                    const uint4 qa = *(const uint4 *)&slots[b * 2 + rot].w[0], qb = *(const uint4 *)&slots[b * 2 + rot].w[4];
+                    w0 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.y);
+                    w2 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.w);
+                    w4 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.x), w5 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.y);
+                    if (rot == 0) hsh = (uint32_t)__builtin_amdgcn_readfirstlane(qb.z);
+                } else {
+                    const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].item);
+                    const uint32_t flg = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].flags);
+                    uint32_t ww[6];
+                    make_slot_words<W, L>(item, rot, kResets && (flg & 2u) != 0u, ROT, p.H, ww);
+                    w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4], w5 = ww[5];
+                    if (rot == 0 && draw) hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + b));
+                }
                 const uint32_t od = w0 & 0xffffffu;
                 const int nj = (int)(w0 >> 24), nv = (int)(w1 & 0xffffu), hz1 = (int)((w1 >> 16) & 0x1ffu);
                 const bool valid = (w1 >> 28) & 1u, big = (w1 >> 29) & 1u, fresh = (w1 >> 30) & 1u, square = (w1 >> 31) & 1u;
