@@ -34,9 +34,10 @@ struct alignas(16) float4 {
     float x, y, z, w;
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
-struct uint4 {
+struct alignas(16) uint4 {
     unsigned x, y, z, w;
 };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct alignas(8) uint2 {
     unsigned x, y;
 };
