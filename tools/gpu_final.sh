@@ -1,0 +1,25 @@
+#!/bin/bash
+# The round's evidence set for the current build: tools/gpu_measure.sh <tag> (suite, benches, rocprofv3 stats, PMC,
+# sweep) plus phase timelines, the stream-mode bench and the multi-rank bench paths on one device.
+set -u
+TAG=${1:-final}
+R=/root/repo
+O=$R/gpurun_out/$TAG
+cd $R
+tools/gpu_measure.sh $TAG
+export TMPDIR=/tmp
+if [ -f $R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so ]; then
+  for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768"; do
+    name=${cfg%%:*}; args=${cfg#*:}
+    BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so python tools/phase_timeline.py $args > $O/timeline_$name.json 2>> $O/bench.err
+  done
+  BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so bash tools/probe_marginal_cost.sh > $O/marginal_cost.txt 2>&1
+fi
+python bench.py --no-cpu-baseline --stream > $O/bench_stream.json 2>> $O/bench.err
+BPP_BENCH_BACKEND=gloo BPP_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 20 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_gloo_one_device.json
+BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --warmup 20 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
+timeout 600 python tools/sweep_bins.py --size 20 20 20 --bins 32768 131072 > $O/sweep_bins_20.jsonl 2>> $O/sweep.err
+python tools/bench_mask_kernels.py > $O/mask_and_reset_kernels.json 2>> $O/bench.err
+python tools/bench_masked_act.py > $O/masked_act_timing.json 2>> $O/bench.err
+ls $O | head -50
