@@ -13,7 +13,6 @@ if [ -f $R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so ]; then
     name=${cfg%%:*}; args=${cfg#*:}
     BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so python tools/phase_timeline.py $args > $O/timeline_$name.json 2>> $O/bench.err
   done
-  BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so bash tools/probe_marginal_cost.sh > $O/marginal_cost.txt 2>&1
 fi
 python bench.py --no-cpu-baseline --stream > $O/bench_stream.json 2>> $O/bench.err
 BPP_BENCH_BACKEND=gloo BPP_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
