@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: what a float4 copy kernel reaches (79 % of the spec peak)
 
 
 def algorithmic_bytes_per_env_step(A, M):
@@ -144,6 +145,17 @@ def profile_evidence(key):
     except Exception:
         pass
     return None
+
+
+def limiter(moved_gbs, valu_util):
+    """What the counters say holds the kernel back: the memory side when the bytes it really moves come close to what a
+    copy kernel achieves, the vector ALUs when they are the busier resource."""
+    if moved_gbs is None or valu_util is None:
+        return None
+    mem = moved_gbs / HBM_ACHIEVABLE_GBS
+    return ("hbm: moves %.0f %% of the 6.3 TB/s a copy kernel achieves (VALU pipes %.0f %% busy)" % (100 * mem, 100 * valu_util)
+            if mem >= valu_util else
+            "valu issue: VALU pipes %.0f %% busy (memory side at %.0f %% of the achievable 6.3 TB/s)" % (100 * valu_util, 100 * mem))
 
 
 def main():
@@ -302,7 +314,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
                          "achieved_moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
-                         "limiter": (ev or {}).get("limiter"), "valu_utilisation": (ev or {}).get("valu_utilisation"),
+                         "frac_moved_of_achievable": (moved / HBM_ACHIEVABLE_GBS) if moved else None,
+                         "valu_utilisation": (ev or {}).get("valu_utilisation"),
+                         "limiter": limiter(moved, (ev or {}).get("valu_utilisation")),
                          "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
                          "launch_us_min": kern_ms[0] * 1e3},
         }

@@ -50,8 +50,6 @@ def main():
             "lds_instructions": int(c["SQ_INSTS_LDS"]), "waves": int(c["SQ_WAVES"]),
             "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0),
             "valu_utilisation": round(util, 3),
-            "limiter": ("valu issue (VALU pipes busy %.0f %% of the kernel)" % (100 * util)) if util > 0.6 else
-                       "memory / latency (VALU pipes busy %.0f %% of the kernel)" % (100 * util),
             "source": os.path.relpath(os.path.abspath(path), ROOT),
         }
     json.dump(out, open(out_path, "w"), indent=1)
