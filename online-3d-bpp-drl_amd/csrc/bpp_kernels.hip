@@ -2014,16 +2014,21 @@ int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t 
     // same generator as the device stream (bpp_stream_gen.inl), one private random.Random(seed0 + k) per row
     const int st = run_rows_threaded(n, threads, [=](int k0, int k1) {
         std::vector<uint32_t> mt(624);
-        std::vector<CutBox> boxes((size_t)stream_work_entries(W, L, H, bound_lo));
+        const int maxn = stream_work_entries(W, L, H, bound_lo);
+        std::vector<CutBox> boxes((size_t)maxn);
+        std::vector<uint32_t> cut((size_t)maxn);
         const uint32_t term = (uint32_t)W | ((uint32_t)L << 8) | ((uint32_t)H << 16);
         int over = 0;
         for (int k = k0; k < k1; ++k) {
             StridedMT rng{mt.data(), 1, 624};
             rng.seed(seed0 + (uint64_t)k);
-            StridedWork work{boxes.data(), 1};
+            ArrayWork work{boxes.data()};
+            ArrayVals vals{cut.data()};
             uint32_t *row = (uint32_t *)pool + (size_t)k * T;
-            const int cnt = cut2_generate(rng, work, W, L, H, bound_lo, bound_hi, row, T - 1);
-            for (int t = cnt < T - 1 ? cnt : T - 1; t < T; ++t) row[t] = term;
+            const int cnt = cut2_generate(rng, work, vals, W, L, H, bound_lo, bound_hi);
+            const int nw = cnt < T - 1 ? cnt : T - 1;
+            for (int t = 0; t < nw; ++t) row[t] = cut[(size_t)t] & 0x00ffffffu;
+            for (int t = nw; t < T; ++t) row[t] = term;
             if (lengths) lengths[k] = cnt;
             over |= cnt > T - 1;
         }
@@ -2129,7 +2134,8 @@ int bpp_stream_init(const bpp_stream *s, void *stream) {
 int bpp_stream_refill(const bpp_stream *s, void *stream) {
     int rc = check_stream(s);
     if (rc) return rc;
-    hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *s);
+    hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + kStreamLanes - 1) / kStreamLanes), dim3(kStreamLanes),
+                       (size_t)kStreamLdsWords * kStreamLanes * 4, (hipStream_t)stream, *s);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }

@@ -13,10 +13,11 @@
 // sequence `random.Random(seed0 + id)` yields through the reference creator.  It is written once for host and
 // device: `Rng` supplies u32(), `Work` the pending-box list.
 
-// pending box: a = x | y << 8 | z << 16, b = low | high << 8   (all <= 255)
+// pending box: a = x | y << 8 | z << 16, b = low | high << 8 | alive << 31   (sides and heights <= 255)
 struct CutBox {
     uint32_t a, b;
 };
+constexpr uint32_t kAlive = 0x80000000u;
 
 template <class Rng>
 __host__ __device__ inline uint32_t rand_below(Rng &rng, uint32_t n) {   // Random._randbelow_with_getrandbits(n), 0 < n < 2^32
@@ -27,18 +28,31 @@ __host__ __device__ inline uint32_t rand_below(Rng &rng, uint32_t n) {   // Rand
     return x;
 }
 
-// One CUT-2 sequence into `row` (packed x | y<<8 | z<<16, top byte 0; at most cap items are stored), every box side in
-// [lo, hi].  `work(i)` addresses the pending list (capacity >= W*L*H / lo^3 + 8).  Returns the number of items.
-template <class Rng, class Work>
-__host__ __device__ inline int cut2_generate(Rng &rng, Work &work, int W, int L, int H, int lo, int hi, uint32_t *row, int cap) {
-    int nv = 0, ni = 0;
-    work(ni++) = CutBox{(uint32_t)W | ((uint32_t)L << 8) | ((uint32_t)H << 16), 0u | ((uint32_t)H << 8)};
-    while (ni) {
-        int i = 0;
-        while (i < ni) {                        // `for box in invalid_box` with remove/append inside, mdCreator.py:121-130
-            const CutBox b = work(i++);
+// One CUT-2 sequence, every box side in [lo, hi].  `work` is the pending list (get / set by index, capacity >=
+// W*L*H / lo^3 + 8), `vals` collects the cut boxes as x | y<<8 | z<<16 | base height<<24 and sorts them.  Returns the
+// number of items.
+//
+// The reference walks `invalid_box` with a `for` loop while removing the box just split and appending its oversized
+// parts (mdCreator.py:117-135): a removal slides the rest of the list one place to the left under the iterator, which
+// therefore SKIPS the element that followed the removed one; appended parts are visited in the same pass; the outer
+// `while True` starts over until the list is empty.  Here the list is never shifted: a split box is marked dead, the
+// element after it (dead ones do not count) is skipped once, and the survivors are compacted between passes -- the
+// same visiting order, hence the same draws, without the O(n) shift per split.
+template <class Rng, class Work, class Vals>
+__host__ __device__ inline int cut2_generate(Rng &rng, Work &work, Vals &vals, int W, int L, int H, int lo, int hi) {
+    int nv = 0, tail = 0;
+    work.set(tail++, CutBox{(uint32_t)W | ((uint32_t)L << 8) | ((uint32_t)H << 16), 0u | ((uint32_t)H << 8) | kAlive});
+    for (;;) {
+        bool skip = false;
+        for (int i = 0; i < tail; ++i) {        // `for box in invalid_box`, appended boxes included
+            const CutBox b = work.get(i);
+            if (!(b.b & kAlive)) continue;
+            if (skip) {                         // this box slid under the iterator when its predecessor was removed
+                skip = false;
+                continue;
+            }
             const int bx = b.a & 255u, by = (b.a >> 8) & 255u, bz = (b.a >> 16) & 255u, low = b.b & 255u, high = (b.b >> 8) & 255u;
-            int flags[3], nf = 0;               // :60-66
+            int flags[3], nf = 0;               // mdCreator.py:60-66
             if (bx > hi) flags[nf++] = 0;
             if (by > hi) flags[nf++] = 1;
             if (bz > hi) flags[nf++] = 2;
@@ -63,33 +77,39 @@ __host__ __device__ inline int cut2_generate(Rng &rng, Work &work, int W, int L,
                 s1[0] = bx, s1[1] = by, s1[2] = bz - r, s1[3] = low, s1[4] = high - r;
                 s2[0] = bx, s2[1] = by, s2[2] = r, s2[3] = high - r, s2[4] = high;
             }
-            for (int k = i; k < ni; ++k) work(k - 1) = work(k);   // invalid_box.remove(box)
-            --ni;
+            work.set(i, CutBox{b.a, b.b & ~kAlive});   // invalid_box.remove(box)
+            skip = true;
             for (int part = 0; part < 2; ++part) {
                 const int *c = part ? s2 : s1;
                 const bool ok = c[0] >= lo && c[0] <= hi && c[1] >= lo && c[1] <= hi && c[2] >= lo && c[2] <= hi;
-                if (ok) {
-                    if (nv < cap) row[nv] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
-                    ++nv;
-                } else {
-                    work(ni++) = CutBox{(uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16),
-                                        (uint32_t)c[3] | ((uint32_t)c[4] << 8)};
-                }
+                if (ok)
+                    vals.set(nv++, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
+                else
+                    work.set(tail++, CutBox{(uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16),
+                                            (uint32_t)c[3] | ((uint32_t)c[4] << 8) | kAlive});
             }
         }
+        int alive = 0;                          // compact the survivors (order kept) for the next pass
+        for (int i = 0; i < tail; ++i) {
+            const CutBox b = work.get(i);
+            if (b.b & kAlive) {
+                if (alive != i) work.set(alive, b);
+                ++alive;
+            }
+        }
+        tail = alive;
+        if (tail == 0) break;
     }
-    // depart_box (:137-138): stable sort by the height of the base (kept in the top byte so far), then drop the key
-    const int n = nv < cap ? nv : cap;
-    for (int a = 1; a < n; ++a) {
-        const uint32_t v = row[a];
+    // depart_box (:137-138): stable sort by the height of the base (the top byte), insertion sort
+    for (int a = 1; a < nv; ++a) {
+        const uint32_t v = vals.get(a);
         int k = a - 1;
-        while (k >= 0 && (row[k] >> 24) > (v >> 24)) {
-            row[k + 1] = row[k];
+        while (k >= 0 && (vals.get(k) >> 24) > (v >> 24)) {
+            vals.set(k + 1, vals.get(k));
             --k;
         }
-        row[k + 1] = v;
+        vals.set(k + 1, v);
     }
-    for (int a = 0; a < n; ++a) row[a] &= 0x00ffffffu;
     return nv;
 }
 
@@ -150,15 +170,117 @@ struct StridedMT {
     }
 };
 
-struct StridedWork {
+// host-side storages (bpp_gen_cut2): plain arrays
+struct ArrayWork {
     CutBox *base;
-    size_t stride;
-    __host__ __device__ CutBox &operator()(int i) { return base[(size_t)i * stride]; }
+    CutBox get(int i) const { return base[i]; }
+    void set(int i, CutBox v) { base[i] = v; }
+};
+struct ArrayVals {
+    uint32_t *base;
+    uint32_t get(int i) const { return base[i]; }
+    void set(int i, uint32_t v) { base[i] = v; }
 };
 
 constexpr int kStreamMtWords = 625;   // 624 state words + the index
 
 __host__ __device__ inline int stream_work_entries(int W, int L, int H, int lo) { return W * L * H / (lo * lo * lo) + 8; }
+
+// ---- device side: one lane per bin, the hot state in LDS -------------------------------------------------------------
+// Every access of the list walk is a dependent round trip, so where the lists live decides the kernel's speed: the
+// first kStreamPendCap pending boxes and kStreamValCap cut boxes of a lane sit in LDS (word w of lane l at
+// lds[w * 64 + l]: conflict-free), anything beyond -- rare -- spills to the caller's global `work` array.  The
+// generator draws from a 32-word LDS buffer of tempered outputs refilled with 32 independent loads, and twists its
+// state in chunks of 16 words (17 + 16 independent loads, then 16 stores) instead of word by word.
+constexpr int kStreamLanes = 64;        // threads per workgroup of the refill kernel
+constexpr int kStreamPendCap = 48;
+constexpr int kStreamValCap = 64;
+constexpr int kStreamRngBuf = 32;
+constexpr int kStreamLdsWords = 2 * kStreamPendCap + kStreamValCap + kStreamRngBuf;   // per lane
+
+struct LdsWork {
+    uint32_t *lds;      // this lane's column of the pending area: word w at lds[w * 64]
+    CutBox *spill;      // global: entry i >= cap at spill[(i - cap) * stride]
+    size_t stride;
+    __device__ CutBox get(int i) const {
+        if (i < kStreamPendCap) return CutBox{lds[(2 * i) * kStreamLanes], lds[(2 * i + 1) * kStreamLanes]};
+        return spill[(size_t)(i - kStreamPendCap) * stride];
+    }
+    __device__ void set(int i, CutBox v) {
+        if (i < kStreamPendCap) {
+            lds[(2 * i) * kStreamLanes] = v.a;
+            lds[(2 * i + 1) * kStreamLanes] = v.b;
+        } else {
+            spill[(size_t)(i - kStreamPendCap) * stride] = v;
+        }
+    }
+};
+struct LdsVals {
+    uint32_t *lds;      // this lane's column of the value area
+    uint32_t *row;      // global: the pool row itself takes what does not fit (entry i at row[i])
+    int cap;            // entries of the row that may be written (T - 1)
+    __device__ uint32_t get(int i) const { return i < kStreamValCap ? lds[i * kStreamLanes] : (i < cap ? row[i] : 0u); }
+    __device__ void set(int i, uint32_t v) {
+        if (i < kStreamValCap) lds[i * kStreamLanes] = v;
+        else if (i < cap) row[i] = v;
+    }
+};
+
+// CPython's random.Random for one bin: state words in global memory (word i of bin e at mt[i * E + e]), tempered outputs
+// handed out from an LDS buffer.
+struct BufferedMT {
+    uint32_t *mt;       // &mt[e]
+    size_t stride;      // E
+    uint32_t *buf;      // this lane's column of the output buffer
+    int idx;            // next state word to temper (0..624)
+    int have, pos;      // buffered outputs, next one to hand out
+    __device__ void twist() {
+        for (int k0 = 0; k0 < 624; k0 += 16) {
+            uint32_t cur[17], far[16];
+#pragma unroll
+            for (int q = 0; q < 17; ++q) {
+                const int k = k0 + q;
+                cur[q] = mt[(size_t)(k < 624 ? k : 0) * stride];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = k0 + q;
+                far[q] = k < 624 ? mt[(size_t)(k + 397 < 624 ? k + 397 : k - 227) * stride] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = k0 + q;
+                if (k < 624) {
+                    const uint32_t y = (cur[q] & 0x80000000u) | (cur[q + 1] & 0x7fffffffu);
+                    mt[(size_t)k * stride] = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+            }
+        }
+        idx = 0;
+    }
+    __device__ uint32_t u32() {
+        if (pos >= have) {
+            if (idx >= 624) twist();
+            const int n = 624 - idx < kStreamRngBuf ? 624 - idx : kStreamRngBuf;
+            uint32_t y[kStreamRngBuf];
+#pragma unroll
+            for (int q = 0; q < kStreamRngBuf; ++q) y[q] = q < n ? mt[(size_t)(idx + q) * stride] : 0u;
+#pragma unroll
+            for (int q = 0; q < kStreamRngBuf; ++q) {
+                uint32_t v = y[q];
+                v ^= v >> 11;
+                v ^= (v << 7) & 0x9d2c5680u;
+                v ^= (v << 15) & 0xefc60000u;
+                v ^= v >> 18;
+                if (q < n) buf[q * kStreamLanes] = v;
+            }
+            idx += n;
+            have = n;
+            pos = 0;
+        }
+        return buf[(pos++) * kStreamLanes];
+    }
+};
 
 // One lane per bin: seed the bin's generator with random.Random(seed0 + global id); nothing generated yet.
 __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
@@ -172,25 +294,33 @@ __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
 
 // One lane per bin: cut new sequences into the ring until the bin has `depth` episodes available from its current
 // one (rows of episodes the bin has finished are the ones overwritten).
-__global__ __launch_bounds__(256) void stream_refill_kernel(bpp_stream s) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= s.num_envs) return;
+__global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds = (uint32_t *)smem;
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * kStreamLanes + lane;
+    if (e >= s.num_envs) return;     // no workgroup-level synchronisation below
     const int E = s.num_envs, T = s.pool_len, D = s.depth;
     const int cur = s.state[e].episode;
     int g = s.gen_next[e];
     if (g >= cur + D) return;
-    StridedMT rng{s.mt + e, (size_t)E, (int)s.mt[(size_t)624 * E + e]};
-    StridedWork work{(CutBox *)s.work + e, (size_t)E};
+    BufferedMT rng{s.mt + e, (size_t)E, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
+                   (int)s.mt[(size_t)624 * E + e], 0, 0};
+    LdsWork work{lds + lane, (CutBox *)s.work + e, (size_t)E};
     const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
     int over = 0;
     while (g < cur + D) {
         uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
-        const int n = cut2_generate(rng, work, s.W, s.L, s.H, s.bound_lo, s.bound_hi, row, T - 1);
+        LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1};
+        const int n = cut2_generate(rng, work, vals, s.W, s.L, s.H, s.bound_lo, s.bound_hi);
         over += n > T - 1;
-        for (int t = n < T - 1 ? n : T - 1; t < T; ++t) row[t] = term;   // pad with the terminator (last entry always)
+        const int nw = n < T - 1 ? n : T - 1;
+        for (int t = 0; t < nw; ++t) row[t] = vals.get(t) & 0x00ffffffu;   // drop the sort key
+        for (int t = nw; t < T; ++t) row[t] = term;                        // pad with the terminator (last entry always)
         ++g;
     }
-    s.mt[(size_t)624 * E + e] = (uint32_t)rng.idx;
+    // buffered but unused outputs are handed out again next time: remember the index of the next unused state word
+    s.mt[(size_t)624 * E + e] = (uint32_t)(rng.idx - (rng.have - rng.pos));
     s.gen_next[e] = g;
     if (over && s.overflow) atomicAdd(s.overflow, over);
 }
