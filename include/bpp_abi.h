@@ -163,7 +163,8 @@ typedef struct bpp_knobs {
     int32_t ablate;           /* profiling builds only (-DBPP_ENABLE_ABLATION): phase bit mask, else ignored    */
     int32_t legacy_fast;      /* 1 = run the runtime-geometry prefix-image kernel (bpp_fast_kernel) also for the
                                  10x10 / 20x20 bins that have a compiled tile kernel (bpp_tile_kernel)          */
-    int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = default (4)  */
+    int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = by size (1, or 2 / 4
+                                 once a launch's outputs exceed the Infinity Cache) */
     int32_t reserved[1];
 } bpp_knobs;
 int bpp_get_knobs(bpp_knobs *out);

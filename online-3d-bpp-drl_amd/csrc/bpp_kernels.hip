@@ -1599,9 +1599,10 @@ struct Launch {
 // per wave.  Any other bin with W*L % 4 == 0 and H <= 22 -- and these, when the launch-shape knobs are set --
 // runs bpp_fast_kernel with runtime geometry.
 struct TileGeoEntry {
-    int W, L, K, epw, nit;   // nit: default number of groups per wave of the step kernel
-};
-constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1}, {20, 20, 1, 1, 1}, {20, 20, 2, 1, 1}, {10, 10, 2, 4, 1}};
+    int W, L, K, epw, nit, nit_big;   // groups per wave of the step kernel: default / when the outputs of one
+};                                    // launch exceed the 256 MiB Infinity Cache (measured)
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1, 2}, {20, 20, 1, 1, 1, 4}, {20, 20, 2, 1, 1, 4}, {10, 10, 2, 4, 1, 2}};
+constexpr size_t kOutputsPastL3 = 300u * 1000u * 1000u;   // obs + mask bytes per launch
 constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
 
@@ -1705,7 +1706,9 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     l.blocks = (waves + l.wpb - 1) / l.wpb;
     l.lds = (size_t)l.wpb * p.lds_per_wave;
     if (l.tile >= 0) {   // the tile kernel's launch shape is part of its type; only the grid depends on E
-        l.nit = (kn.tile_groups == 1 || kn.tile_groups == 2 || kn.tile_groups == 4) ? kn.tile_groups : kTileGeo[l.tile].nit;
+        const bool past_l3 = (size_t)E * (size_t)(16 * p.A + 4 * p.M) > kOutputsPastL3;
+        l.nit = (kn.tile_groups == 1 || kn.tile_groups == 2 || kn.tile_groups == 4)
+                    ? kn.tile_groups : (past_l3 ? kTileGeo[l.tile].nit_big : kTileGeo[l.tile].nit);
         const int nb = kTileWaves * kTileGeo[l.tile].epw * l.nit;   // step kernel; reset / mask kernels: one group
         p.epw = kTileGeo[l.tile].epw;
         l.wpb = kTileWaves;
