@@ -227,14 +227,23 @@ def main():
     env.rollout_uniform(seed=1, step0=0, nsteps=args.warmup, actions=actions)
     stats.collect(env).all_reduce()   # also loads the few torch kernels the collection uses
     stats.zero_()
-    # timed region = EXACTLY K lock-steps between two fences; repeated `reps` times back to back and the
-    # MEDIAN repetition reported, so that a small K is not a single sub-millisecond sample
+    # timed region = EXACTLY K lock-steps: barrier + synchronize, clock, K lock-steps, synchronize, clock (the maximum
+    # over ranks is taken afterwards); repeated `reps` times and the MEDIAN repetition reported, so that a small K is not
+    # a single sub-millisecond sample.  The path's only collective -- the 32-byte statistics all-reduce -- runs inside
+    # the timed region once per logging interval of LOG_INTERVAL lock-steps, the reference's own cadence
+    # (main.py:194-: every log_interval = 10 updates of num_steps = 5 lock-steps).
+    LOG_INTERVAL = 50
+    since_log = [0]
+
     def timed_region(step0):
         fence()
         t0 = time.perf_counter()
         env.rollout_uniform(seed=1, step0=step0, nsteps=args.steps, actions=actions)
-        stats.collect(env).all_reduce()   # the only collective of the path: 32 bytes, once per logging interval
-        fence()
+        since_log[0] += args.steps
+        if since_log[0] >= LOG_INTERVAL:
+            stats.collect(env).all_reduce()
+            since_log[0] = 0
+        torch.cuda.synchronize(device)
         return time.perf_counter() - t0
 
     first = timed_region(args.warmup)
@@ -250,6 +259,7 @@ def main():
         samples = tm.cpu().tolist()
     dt = sorted(samples)[len(samples) // 2]
     done_steps = args.warmup + reps * args.steps
+    stats.collect(env).all_reduce()   # whatever finished since the last logging point (outside the timed regions)
     # same K lock-steps driven step by step from Python (what a Python RL loop pays per step)
     fence()
     t1 = time.perf_counter()
@@ -290,7 +300,7 @@ def main():
             "value": world * E * args.steps / dt,
             "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "reps": reps, "rep_ms_per_step_min_median_max": [min(samples) / args.steps * 1e3, dt / args.steps * 1e3,
+            "reps": reps, "stats_all_reduce_every_lock_steps": LOG_INTERVAL, "rep_ms_per_step_min_median_max": [min(samples) / args.steps * 1e3, dt / args.steps * 1e3,
                                                             max(samples) / args.steps * 1e3],
             "ms_per_step": dt / args.steps * 1e3,
             "python_loop_ms_per_step": dt_py / args.steps * 1e3,
