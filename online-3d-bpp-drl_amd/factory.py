@@ -2,6 +2,7 @@
 
     envs = make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets, args=args)
 
+Pass `stream=dict(bound=(lo, hi), seed=s, depth=D)` instead of a pool for the endless device-generated CUT-2 supply.
 `args` is the reference's argparse namespace (acktr/arguments.py): `container_size`, `enable_rotation`,
 `data_type` ('cut1' | 'cut2' | 'rs', bin3D.py:21-32) and `box_size_set` are honoured; `gamma`, `log_dir`,
 `allow_early_resets`, `num_frame_stack` are accepted for signature compatibility (the reference disables
@@ -36,7 +37,7 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
         raise ValueError("args (the reference's argparse namespace) is required")
     size = tuple(int(v) for v in args.container_size)
     rot = bool(getattr(args, "enable_rotation", False))
-    if pool is None:
+    if pool is None and env_kwargs.get("stream") is None:
         pool = make_pool(size, getattr(args, "data_type", getattr(args, "item_seq", "cut2")),
                          getattr(args, "box_size_set", None), rot, seed=int(seed), pool_size=pool_size)
     env_kwargs.setdefault("fresh_outputs", True)   # reference semantics: earlier results stay valid

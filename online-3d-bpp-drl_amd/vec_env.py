@@ -473,6 +473,9 @@ class BppVecEnv(object):
         last observation and its mask."""
         sd = {"hmap": self.hmap.clone(), "state": self.state.clone(), "stats": self.stats_slots.clone(),
               "first_reset": self._first_reset}
+        if self._stream is not None:   # streaming supply: the ring, every bin's generator and its progress
+            sd.update(stream_ring=self.pool.clone(), stream_mt=self._mt.clone(), stream_gen_next=self.gen_next.clone(),
+                      stream_since_refill=self._since_refill)
         if self._bufs is not None:
             sd["obs"] = self._bufs["obs"].clone()
             if self._bufs["mask"] is not None:
@@ -485,6 +488,13 @@ class BppVecEnv(object):
         if "stats" in sd:
             self.stats_slots.copy_(sd["stats"])
         self._first_reset = bool(sd["first_reset"])
+        if self._stream is not None:
+            if "stream_ring" not in sd:
+                raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
+            self.pool.copy_(sd["stream_ring"])
+            self._mt.copy_(sd["stream_mt"])
+            self.gen_next.copy_(sd["stream_gen_next"])
+            self._since_refill = int(sd["stream_since_refill"])
         if "obs" in sd:
             bufs, _ = self._buffers()
             if self._res is None or self.fresh_outputs:

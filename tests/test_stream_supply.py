@@ -120,3 +120,30 @@ def test_gpu_stream_supply_matches_oracle_and_python_random(oracle, size, rot, E
             return self.env.state_numpy()
 
     spec_check(GpuStreamEnv, oracle, size, rot, E, steps, depth, refill, native)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_env_checkpoint_resume_and_factory():
+    """state_dict() of a streaming env carries the ring and every bin's generator: a fresh env resumes identically;
+    make_vec_envs accepts stream=... in place of a pool."""
+    import types
+    import torch
+    import bpp_amd
+    size, E = (10, 10, 10), 300
+    spec = dict(bound=(2, 5), seed=5, depth=6, refill_every=3)
+    env = bpp_amd.BppVecEnv(E, size, enable_rotation=True, stream=spec)
+    env.reset()
+    env.rollout_uniform(seed=3, step0=0, nsteps=17)
+    ckpt = env.state_dict()
+    first = env.rollout_uniform(seed=3, step0=17, nsteps=23)
+    want = {k: getattr(first, k).clone() for k in ("obs", "mask", "counter", "ratio", "ep_ret")}
+    other = bpp_amd.BppVecEnv(E, size, enable_rotation=True, stream=spec)
+    other.load_state_dict(ckpt)
+    again = other.rollout_uniform(seed=3, step0=17, nsteps=23)
+    for k, v in want.items():
+        assert torch.equal(getattr(again, k), v), k
+    assert torch.equal(other.state, env.state) and torch.equal(other.gen_next, env.gen_next)
+    args = types.SimpleNamespace(container_size=size, enable_rotation=False, data_type="cut2", box_size_set=None)
+    envs = bpp_amd.make_vec_envs("Bpp-v0", 1, 16, 1.0, None, "cuda:0", False, args=args, stream=spec)
+    obs = envs.reset()
+    assert tuple(obs.shape) == (16, 400) and envs._stream is not None
