@@ -1265,7 +1265,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t 
 // Masked categorical action selection (include/bpp_abi.h: bpp_masked_act; acktr/distributions.py:71-84,
 // acktr/model.py:56-68).  16 lanes per bin, PER float4 quads of logits and mask per lane; row maximum,
 // softmax denominator, probability total and the CDF position are reduced/scanned inside the 16-lane row
-// with shuffles.  float32 throughout (expf/logf, not the fast intrinsics).
+// with shuffles.  float32 throughout; exp through the hardware exp2 (__expf, ~2 ulp) and one reciprocal of the softmax
+// denominator per row -- both far inside the 5e-6 log-probability tolerance the torch reference is held to.
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
     for (int d = 8; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 16));
@@ -1310,10 +1311,11 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
     for (int k = 0; k < PER; ++k)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            z[k][t] = in[k] ? expf(z[k][t] - mx) : 0.0f;
+            z[k][t] = in[k] ? __expf(z[k][t] - mx) : 0.0f;
             part += z[k][t];
         }
     const float sum = row16_sum(part);
+    const float inv_sum = 1.0f / sum;
     float qtot[PER];
     float lane_tot = 0.0f, best = -1.0f;
     int best_i = 0;
@@ -1322,7 +1324,7 @@ __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, co
         qtot[k] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float pk = in[k] ? z[k][t] / sum + 1e-5f : 0.0f;  // distributions.py:79-80
+            const float pk = in[k] ? z[k][t] * inv_sum + 1e-5f : 0.0f;  // distributions.py:79-80
             z[k][t] = pk;
             qtot[k] += pk;
             if (in[k] && pk > best) {

@@ -146,6 +146,7 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t acc) {
     const int l = emu::lane_id();
     return acc + (uint32_t)(l <= 32 ? 0 : __builtin_popcount(mask & ((1u << (l - 32)) - 1u)));
 }
+#define __expf(x) expf(x)   // (glibc declares a function of that name)
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
