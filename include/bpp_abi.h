@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 6
+#define BPP_ABI_VERSION 7
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -224,6 +224,19 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
  * float32 arithmetic; logits, mask: [E][M] float32; action: [E] int64; log_prob: [E] float32 (may be NULL). */
 int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
                    int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream);
+
+/* Training half of the same head (acktr/distributions.py:71-101 as consumed by Policy.evaluate_actions,
+ * acktr/model.py:90-96), forward and backward, float32:
+ *     log_prob[e] = dist.log_probs(action)[e]            (log of the clamped normalised probability of action[e])
+ *     entropy[e]  = dist.entropy()[e]                    (the loop takes its mean)
+ *     bad_prob[e] = sum_k softmax(logits)[e,k] * (1 - mask[e,k])   (row sums of `bx`; `prob_loss` is their sum / (E*M))
+ * bpp_masked_evaluate_backward writes d(sum_e g_log_prob[e]*log_prob[e] + g_entropy[e]*entropy[e] + g_bad_prob[e]*bad_prob[e])
+ * / d logits into grad_logits [E][M].  One wave per bin, any M. */
+int bpp_masked_evaluate(const float *logits, const float *mask, const int64_t *action, float *log_prob, float *entropy,
+                        float *bad_prob, int32_t E, int32_t M, void *stream);
+int bpp_masked_evaluate_backward(const float *logits, const float *mask, const int64_t *action, const float *g_log_prob,
+                                 const float *g_entropy, const float *g_bad_prob, float *grad_logits, int32_t E, int32_t M,
+                                 void *stream);
 
 /* Host-side CUT-2 item-sequence generator, multithreaded.  Restates
  * envs/bpp0/mdCreator.py:59-166 (Box.benchmark_split, bin.gen_benchmark incl. its iterate-while-mutating

@@ -15,7 +15,7 @@ LIB = os.environ.get("BPP_HIP_LIB") or os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
@@ -23,7 +23,7 @@ STATS_SLOTS = 256
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward"]
 
 
 class Batch(ctypes.Structure):
@@ -115,6 +115,8 @@ def lib():
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_evaluate_backward.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
         L.bpp_gen_cut1.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32,
                                                                                      ctypes.c_uint64, ctypes.c_int32]

@@ -1497,6 +1497,109 @@ __global__ __launch_bounds__(256) void masked_act_kernel_generic(const float *lo
     }
 }
 
+// Training half of the masked policy head (acktr/distributions.py:71-101 as used by Policy.evaluate_actions,
+// acktr/model.py:90-96): for the actions taken, one wave per bin computes
+//   logp  = log(clamp(p[a]))            p = lx / sum(lx), lx = softmax(x - 14 (1 - mask)) + 1e-5   (dist.log_probs)
+//   ent   = -sum_k p_k log(clamp(p_k))                                                           (dist.entropy())
+//   bad   = sum_k softmax(x)_k (1 - mask_k)                                                      (row sum of `bx`)
+// and the backward kernel the gradient of  g_logp * logp + g_ent * ent + g_bad * bad  with respect to the logits
+// (clamp = torch's probs_to_logits clamp to [eps, 1 - eps], derivative 0 outside).
+struct RowStats {
+    float mq, ma, sq, sa, tot;   // maxima and denominators of the masked / plain softmax, sum of lx
+};
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ RowStats masked_row_stats(const float *x, const float *m, int M, int lane) {
+    RowStats r;
+    float mq = -INFINITY, ma = -INFINITY;
+    for (int k = lane; k < M; k += kWave) {
+        mq = fmaxf(mq, x[k] - (1.0f - m[k]) * 14.0f);
+        ma = fmaxf(ma, x[k]);
+    }
+    r.mq = wave_max_f(mq);
+    r.ma = wave_max_f(ma);
+    float sq = 0.0f, sa = 0.0f;
+    for (int k = lane; k < M; k += kWave) {
+        sq += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq);
+        sa += expf(x[k] - r.ma);
+    }
+    r.sq = wave_sum_f(sq);
+    r.sa = wave_sum_f(sa);
+    float tot = 0.0f;
+    for (int k = lane; k < M; k += kWave) tot += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f;
+    r.tot = wave_sum_f(tot);
+    return r;
+}
+constexpr float kProbEps = 1.1920928955078125e-7f;   // torch.finfo(float32).eps, probs_to_logits clamp
+
+__global__ __launch_bounds__(256) void masked_eval_fwd_kernel(const float *logits, const float *mask, const int64_t *action,
+                                                              float *logp, float *entropy, float *bad, int E, int M) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+    const RowStats r = masked_row_stats(x, m, M, lane);
+    float h = 0.0f, b = 0.0f;
+    for (int k = lane; k < M; k += kWave) {
+        const float p = (expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot;
+        h -= p * logf(fminf(fmaxf(p, kProbEps), 1.0f - kProbEps));
+        b += expf(x[k] - r.ma) / r.sa * (1.0f - m[k]);
+    }
+    h = wave_sum_f(h);
+    b = wave_sum_f(b);
+    if (lane == 0) {
+        const int64_t a = action[e];
+        const float pa = (a >= 0 && a < M) ? (expf(x[a] - (1.0f - m[a]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot : kProbEps;
+        logp[e] = logf(fminf(fmaxf(pa, kProbEps), 1.0f - kProbEps));
+        entropy[e] = h;
+        bad[e] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_eval_bwd_kernel(const float *logits, const float *mask, const int64_t *action,
+                                                              const float *g_logp, const float *g_ent, const float *g_bad,
+                                                              float *grad, int E, int M) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+    float *g = grad + (size_t)e * M;
+    const RowStats r = masked_row_stats(x, m, M, lane);
+    const int64_t a = action[e];
+    const float gl = g_logp[e], ge = g_ent[e], gb = g_bad[e];
+    // h_k = dLoss/dp_k
+    auto hk = [&](int k, float p) {
+        const bool inside = p > kProbEps && p < 1.0f - kProbEps;
+        const float pc = fminf(fmaxf(p, kProbEps), 1.0f - kProbEps);
+        float h = -ge * (logf(pc) + (inside ? p / pc : 0.0f));
+        if (k == a) h += inside ? gl / pc : 0.0f;
+        return h;
+    };
+    float c = 0.0f, b = 0.0f;
+    for (int k = lane; k < M; k += kWave) {
+        const float p = (expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot;
+        c += p * hk(k, p);
+        b += expf(x[k] - r.ma) / r.sa * (1.0f - m[k]);
+    }
+    c = wave_sum_f(c);   // sum_j p_j h_j
+    b = wave_sum_f(b);   // bad
+    float v = 0.0f;      // sum_j q_j u_j,  u_j = (h_j - c) / tot
+    for (int k = lane; k < M; k += kWave) {
+        const float q = expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq;
+        v += q * (hk(k, (q + 1e-5f) / r.tot) - c) / r.tot;
+    }
+    v = wave_sum_f(v);
+    for (int k = lane; k < M; k += kWave) {
+        const float q = expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq;
+        const float u = (hk(k, (q + 1e-5f) / r.tot) - c) / r.tot;
+        const float av = expf(x[k] - r.ma) / r.sa;
+        g[k] = q * (u - v) + gb * av * ((1.0f - m[k]) - b);
+    }
+}
+
 // Fallback for rows that are not a multiple of 4 floats or longer than 16 * 8 quads: one wave per bin.
 __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, int64_t *actions, int E, int M,
                                                              int64_t env_id_base, uint64_t seed, uint64_t step) {
@@ -2089,6 +2192,28 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
         default: BPP_ACT(8); break;
     }
 #undef BPP_ACT
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_masked_evaluate(const float *logits, const float *mask, const int64_t *action, float *log_prob, float *entropy,
+                        float *bad_prob, int32_t E, int32_t M, void *stream) {
+    if (!logits || !mask || !action || !log_prob || !entropy || !bad_prob) return fail(BPP_E_BADARG, "bpp_masked_evaluate: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_evaluate: non-positive size");
+    hipLaunchKernelGGL(masked_eval_fwd_kernel, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, mask, action, log_prob,
+                       entropy, bad_prob, E, M);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_masked_evaluate_backward(const float *logits, const float *mask, const int64_t *action, const float *g_log_prob,
+                                 const float *g_entropy, const float *g_bad_prob, float *grad_logits, int32_t E, int32_t M,
+                                 void *stream) {
+    if (!logits || !mask || !action || !g_log_prob || !g_entropy || !g_bad_prob || !grad_logits)
+        return fail(BPP_E_BADARG, "bpp_masked_evaluate_backward: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_evaluate_backward: non-positive size");
+    hipLaunchKernelGGL(masked_eval_bwd_kernel, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, mask, action,
+                       g_log_prob, g_entropy, g_bad_prob, grad_logits, E, M);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }

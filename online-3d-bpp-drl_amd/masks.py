@@ -113,3 +113,52 @@ def masked_act(logits, location_masks, seed=0, step=0, deterministic=False, env_
         _lib.check(_lib.lib().bpp_masked_act(x.data_ptr(), m.data_ptr(), action.data_ptr(), logp.data_ptr(), E, M,
                                              int(env_id_base), int(seed), int(step), int(bool(deterministic)), _stream(dev)))
     return action, logp
+
+
+class _MaskedEvaluate(torch.autograd.Function):
+    """bpp_masked_evaluate / bpp_masked_evaluate_backward as one differentiable op (no saved probabilities:
+    the backward kernel recomputes the row statistics from the logits)."""
+
+    @staticmethod
+    def forward(ctx, logits, location_masks, action):
+        E, M = logits.shape
+        dev = logits.device
+        logp = torch.empty(E, dtype=torch.float32, device=dev)
+        ent = torch.empty(E, dtype=torch.float32, device=dev)
+        bad = torch.empty(E, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().bpp_masked_evaluate(logits.data_ptr(), location_masks.data_ptr(), action.data_ptr(),
+                                                      logp.data_ptr(), ent.data_ptr(), bad.data_ptr(), E, M, _stream(dev)))
+        ctx.save_for_backward(logits, location_masks, action)
+        return logp, ent, bad
+
+    @staticmethod
+    def backward(ctx, g_logp, g_ent, g_bad):
+        logits, location_masks, action = ctx.saved_tensors
+        E, M = logits.shape
+        dev = logits.device
+        g = [torch.zeros(E, dtype=torch.float32, device=dev) if v is None else v.to(torch.float32).contiguous()
+             for v in (g_logp, g_ent, g_bad)]
+        grad = torch.empty_like(logits)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().bpp_masked_evaluate_backward(logits.data_ptr(), location_masks.data_ptr(), action.data_ptr(),
+                                                               g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                                               grad.data_ptr(), E, M, _stream(dev)))
+        return grad, None, None
+
+
+def masked_evaluate(logits, location_masks, action):
+    """Fused, differentiable replacement of `Categorical.forward` + `dist.log_probs(action)` + `dist.entropy()` and of the
+    `bx` term in `Policy.evaluate_actions` (acktr/model.py:90-96, acktr/distributions.py:71-101):
+    logits [E,M] (requires_grad), location_masks [E,M], action int64 [E] or [E,1] ->
+    (action_log_probs [E,1], dist_entropy = dist.entropy().mean(), prob_loss = bad_prob.mean() — the only way the loop
+    consumes `bx`, acktr/algo/acktr_pipeline.py:66)."""
+    if logits.device.type != "cuda":
+        raise RuntimeError("masked_evaluate needs the logits on a HIP device")
+    x = logits.to(torch.float32).contiguous()
+    m = location_masks.to(device=x.device, dtype=torch.float32).contiguous()
+    a = action.to(device=x.device, dtype=torch.int64).reshape(-1).contiguous()
+    if x.shape != m.shape or x.dim() != 2 or a.numel() != x.shape[0]:
+        raise ValueError("logits and location_masks must both be [E, M], action [E]")
+    logp, ent, bad = _MaskedEvaluate.apply(x, m, a)
+    return logp.unsqueeze(1), ent.mean(), bad.sum() / float(x.numel())

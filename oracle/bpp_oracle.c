@@ -486,6 +486,86 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
     return 0;
 }
 
+/* Training half: acktr/distributions.py:71-101 as consumed by Policy.evaluate_actions (acktr/model.py:90-96):
+ * Categorical(probs = softmax(x - 14 (1 - m)) + 1e-5): log_prob of the taken action, entropy, and the row sum of
+ * bx = softmax(x) * (1 - m).  float32, sequential sums. */
+typedef struct { float mq, ma, sq, sa, tot; } row_stats;
+static row_stats masked_row_stats(const float *x, const float *m, int M) {
+    row_stats r = {-INFINITY, -INFINITY, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < M; ++k) {
+        float z = x[k] - (1.0f - m[k]) * 14.0f;
+        if (z > r.mq) r.mq = z;
+        if (x[k] > r.ma) r.ma = x[k];
+    }
+    for (int k = 0; k < M; ++k) {
+        r.sq += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq);
+        r.sa += expf(x[k] - r.ma);
+    }
+    for (int k = 0; k < M; ++k) r.tot += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f;
+    return r;
+}
+static const float kProbEps = 1.1920928955078125e-7f;
+static float clampp(float p) { return p < kProbEps ? kProbEps : (p > 1.0f - kProbEps ? 1.0f - kProbEps : p); }
+
+int bpp_masked_evaluate(const float *logits, const float *mask, const int64_t *action, float *log_prob, float *entropy,
+                        float *bad_prob, int32_t E, int32_t M, void *stream) {
+    (void)stream;
+    if (!logits || !mask || !action || !log_prob || !entropy || !bad_prob) return fail(BPP_E_BADARG, "bpp_masked_evaluate: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_evaluate: non-positive size");
+    for (int e = 0; e < E; ++e) {
+        const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+        row_stats r = masked_row_stats(x, m, M);
+        float h = 0.0f, b = 0.0f;
+        for (int k = 0; k < M; ++k) {
+            float p = (expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot;
+            h -= p * logf(clampp(p));
+            b += expf(x[k] - r.ma) / r.sa * (1.0f - m[k]);
+        }
+        int64_t a = action[e];
+        float pa = (a >= 0 && a < M) ? (expf(x[a] - (1.0f - m[a]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot : kProbEps;
+        log_prob[e] = logf(clampp(pa));
+        entropy[e] = h;
+        bad_prob[e] = b;
+    }
+    return 0;
+}
+
+/* Chain rule through p = lx / sum(lx), lx = q + 1e-5, q = softmax(z): with h = dLoss/dp, c = sum p h,
+ * u = (h - c) / tot, v = sum q u:  dLoss/dx = q (u - v)  +  g_bad * a ((1 - m) - bad),  a = softmax(x). */
+int bpp_masked_evaluate_backward(const float *logits, const float *mask, const int64_t *action, const float *g_log_prob,
+                                 const float *g_entropy, const float *g_bad_prob, float *grad_logits, int32_t E, int32_t M,
+                                 void *stream) {
+    (void)stream;
+    if (!logits || !mask || !action || !g_log_prob || !g_entropy || !g_bad_prob || !grad_logits)
+        return fail(BPP_E_BADARG, "bpp_masked_evaluate_backward: NULL pointer");
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_evaluate_backward: non-positive size");
+    for (int e = 0; e < E; ++e) {
+        const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
+        float *g = grad_logits + (size_t)e * M;
+        row_stats r = masked_row_stats(x, m, M);
+        const int64_t a = action[e];
+        float c = 0.0f, b = 0.0f, v = 0.0f;
+        for (int pass = 0; pass < 3; ++pass)
+            for (int k = 0; k < M; ++k) {
+                float q = expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq;
+                float p = (q + 1e-5f) / r.tot, pc = clampp(p);
+                int inside = p > kProbEps && p < 1.0f - kProbEps;
+                float h = -g_entropy[e] * (logf(pc) + (inside ? p / pc : 0.0f));
+                if (k == a) h += inside ? g_log_prob[e] / pc : 0.0f;
+                float av = expf(x[k] - r.ma) / r.sa;
+                if (pass == 0) {
+                    c += p * h;
+                    b += av * (1.0f - m[k]);
+                } else if (pass == 1) {
+                    v += q * (h - c) / r.tot;
+                } else {
+                    g[k] = q * ((h - c) / r.tot - v) + g_bad_prob[e] * av * ((1.0f - m[k]) - b);
+                }
+            }
+    }
+    return 0;
+}
+
 int bpp_gen_cut2(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H,
                  int32_t bound_lo, int32_t bound_hi, uint64_t seed0, int32_t threads) {
     (void)threads;

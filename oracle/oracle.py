@@ -90,6 +90,8 @@ def lib():
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_evaluate_backward.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
         L.bpp_gen_cut1.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32,
                                                                                      ctypes.c_uint64, ctypes.c_int32]
@@ -238,6 +240,27 @@ def episode_stats(done, ep_ret, ratio, ep_len, acc=None):
         acc = np.zeros(4, np.float64)
     _check(lib().bpp_episode_stats(_p(done), _p(ep_ret), _p(ratio), _p(ep_len), done.shape[0], _p(acc), None))
     return acc
+
+
+def masked_evaluate(logits, mask, action):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    action = np.ascontiguousarray(action, dtype=np.int64).reshape(-1)
+    E, M = logits.shape
+    lp, ent, bad = (np.zeros(E, np.float32) for _ in range(3))
+    _check(lib().bpp_masked_evaluate(_p(logits), _p(mask), _p(action), _p(lp), _p(ent), _p(bad), E, M, None))
+    return lp, ent, bad
+
+
+def masked_evaluate_backward(logits, mask, action, g_lp, g_ent, g_bad):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    action = np.ascontiguousarray(action, dtype=np.int64).reshape(-1)
+    E, M = logits.shape
+    g = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (E,))) for v in (g_lp, g_ent, g_bad)]
+    grad = np.zeros((E, M), np.float32)
+    _check(lib().bpp_masked_evaluate_backward(_p(logits), _p(mask), _p(action), _p(g[0]), _p(g[1]), _p(g[2]), _p(grad), E, M, None))
+    return grad
 
 
 def masked_act(logits, mask, seed, step, deterministic=False, env_id_base=0):

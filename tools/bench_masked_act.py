@@ -37,5 +37,32 @@ for M in (100, 200, 400):
         ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
         res[name + "_us"] = round(sum(ts[5:-5]) / len(ts[5:-5]), 1)
     res["algorithmic_GBps_fused"] = round(E * (8 * M + 12) / (res["fused_hip_us"] * 1e-6) / 1e9, 1)
+    # training half: log-prob + entropy + invalid mass, forward and backward (acktr/model.py:90-96)
+    a = torch.randint(0, M, (E,), device="cuda")
+    adv = torch.randn(E, 1, device="cuda")
+    xg = x.clone().requires_grad_(True)
+
+    def fused_eval(t):
+        xg.grad = None
+        logp, ent, bad = bpp_amd.masked_evaluate(xg, m, a)
+        (-(adv * logp).mean() - 0.01 * ent + 0.1 * bad).backward()
+
+    def eager_eval(t):
+        xg.grad = None
+        d = torch.distributions.Categorical(probs=torch.softmax(xg - (1.0 - m) * 14.0, dim=-1) + 1e-5)
+        bx = torch.softmax(xg, dim=-1) * (1.0 - m)
+        (-(adv * d.log_prob(a).unsqueeze(1)).mean() - 0.01 * d.entropy().mean() + 0.1 * bx.mean()).backward()
+
+    for name, fn in (("fused_hip_evaluate_fwd_bwd", fused_eval), ("torch_eager_evaluate_fwd_bwd", eager_eval)):
+        for t in range(5):
+            fn(t)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for t, (e0, e1) in enumerate(evs):
+            e0.record()
+            fn(t)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        res[name + "_us"] = round(sum(ts[3:-3]) / len(ts[3:-3]), 1)
     out["M=%d" % M] = res
 print(json.dumps({"E": E, "results": out}))
