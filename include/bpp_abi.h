@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 7
+#define BPP_ABI_VERSION 8
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -107,7 +107,11 @@ typedef struct bpp_batch {
  * episodes are available from the current one.  A step reads rows up to two episodes ahead and a bin can finish at
  * most one episode per step: refill at least every depth - 3 lock-steps.  Rows are padded with the terminator
  * (W,L,H); a sequence longer than pool_len - 1 is truncated and counted in `overflow` (size pool_len as
- * W*L*H / bound_lo^3 + 1 to make that impossible). */
+ * W*L*H / bound_lo^3 + 1 to make that impossible -- with rows that long, at most 2048 entries, the refill is the
+ * three-kernel pipeline scan / cut / sort of csrc/bpp_stream_gen.inl, else one lane per bin).
+ * `mt` and `work` are opaque; bpp_stream_sizes tells how large they must be (both 16-byte aligned).  `mt` is an
+ * array of num_envs equal records, one per bin (copy a bin's record together with its ring rows and gen_next to
+ * clone its item stream; checkpoint the whole buffer); `work` is scratch between calls. */
 typedef struct bpp_stream {
     int32_t num_envs;      /* E                                                                    */
     int32_t depth;         /* D >= 4: ring rows per bin                                           */
@@ -117,13 +121,16 @@ typedef struct bpp_stream {
     int64_t env_id_base;   /* global id of local bin 0                                            */
     uint64_t seed0;
     uint8_t *ring;         /* [D][E][T][4] == bpp_batch.seq_pool                                   */
-    uint32_t *mt;          /* [625][E] generator state (opaque)                                    */
-    void *work;            /* [W*L*H / bound_lo^3 + 8][E] 8-byte entries: pending boxes (opaque)   */
+    uint32_t *mt;          /* [E][sizes[0] / E] generator records (opaque)                         */
+    void *work;            /* sizes[1] bytes of scratch (opaque)                                   */
     int32_t *gen_next;     /* [E] next episode index to be generated                               */
     const bpp_env_state *state; /* [E] == bpp_batch.state (read: episode)                          */
     int32_t *overflow;     /* NULL or [1]: incremented per truncated sequence                      */
 } bpp_stream;
 
+/* out[0] = uint32 words of `mt`, out[1] = bytes of `work` for the geometry in *s (num_envs, depth, pool_len, W, L, H
+ * and the bounds filled in; the pointers are not looked at). */
+int bpp_stream_sizes(const bpp_stream *s, int64_t out[2]);
 /* Seed every bin's generator; gen_next = 0.  Call once, then bpp_stream_refill, then bpp_reset. */
 int bpp_stream_init(const bpp_stream *s, void *stream);
 /* Generate until gen_next[e] == state[e].episode + depth for every bin (state must be initialised or zero). */
@@ -165,7 +172,12 @@ typedef struct bpp_knobs {
                                  10x10 / 20x20 bins that have a compiled tile kernel (bpp_tile_kernel)          */
     int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = by size (1, or 2 / 4
                                  once a launch's outputs exceed the Infinity Cache) */
-    int32_t reserved[1];
+    int32_t stream_legacy;    /* bpp_stream_refill: 1 = the one-lane-per-bin refill kernel also where the three-kernel
+                                 pipeline (scan / cut / sort) applies                                          */
+    int32_t stream_overlap;   /* bpp_rollout_uniform_stream: 1 (default) = with depth >= 2 * refill_every + 3 the refills
+                                 run on a high-priority side stream beside the next refill_every lock-steps, 0 = on
+                                 the caller's stream between the lock-steps                                    */
+    int32_t reserved[3];
 } bpp_knobs;
 int bpp_get_knobs(bpp_knobs *out);
 int bpp_set_knobs(const bpp_knobs *k);

@@ -15,14 +15,14 @@ LIB = os.environ.get("BPP_HIP_LIB") or os.path.join(CSRC, "libbpp_hip.so")
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 STATS_SLOTS = 256
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
-           "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_init", "bpp_stream_refill",
+           "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
            "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward"]
 
 
@@ -57,7 +57,8 @@ class Knobs(ctypes.Structure):
     """struct bpp_knobs"""
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
                 ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
-                ("tile_groups", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("tile_groups", ctypes.c_int32), ("stream_legacy", ctypes.c_int32), ("stream_overlap", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 3)]
 
 
 def hipcc():
@@ -123,6 +124,7 @@ def lib():
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_stream_sizes.argtypes = [ctypes.POINTER(Stream), ctypes.POINTER(ctypes.c_int64)]
         L.bpp_stream_init.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
@@ -146,7 +148,8 @@ def get_knobs():
     """Current launch-shape knobs as a dict (include/bpp_abi.h: bpp_knobs)."""
     k = Knobs()
     check(lib().bpp_get_knobs(ctypes.byref(k)))
-    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate", "legacy_fast", "tile_groups")}
+    return {n: int(getattr(k, n)) for n in ("bins_per_wave", "waves_per_group", "xcd_remap", "force_generic", "ablate", "legacy_fast", "tile_groups",
+                                              "stream_legacy", "stream_overlap")}
 
 
 def set_knobs(**kw):
@@ -159,7 +162,7 @@ def set_knobs(**kw):
             raise TypeError("unknown knob %r" % (name,))
         new[name] = int(v)
     k = Knobs(new["bins_per_wave"], new["waves_per_group"], new["xcd_remap"], new["force_generic"], new["ablate"],
-              new["legacy_fast"], new["tile_groups"])
+              new["legacy_fast"], new["tile_groups"], new["stream_legacy"], new["stream_overlap"])
     check(lib().bpp_set_knobs(ctypes.byref(k)))
     return old
 

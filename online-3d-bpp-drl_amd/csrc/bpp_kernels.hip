@@ -1733,6 +1733,8 @@ bpp_knobs current_knobs() {
         g_knobs.ablate = env_int("BPP_ABLATE", 0);
         g_knobs.legacy_fast = env_int("BPP_LEGACY_FAST", 0);
         g_knobs.tile_groups = env_int("BPP_TILE_GROUPS", 0);
+        g_knobs.stream_legacy = env_int("BPP_STREAM_LEGACY", 0);
+        g_knobs.stream_overlap = env_int("BPP_STREAM_OVERLAP", 1);
         g_knobs_init = true;
     }
     return g_knobs;
@@ -2240,18 +2242,83 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
 }  // extern "C"
 
 namespace {
+// One high-priority stream per device for refills that run beside the step kernels (bpp_rollout_uniform_stream).
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t stepped, refilled[2];
+};
+SideStream *side_stream() {
+    static std::mutex mu;
+    static SideStream *per_device[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        SideStream *ss = new SideStream();
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        bool ok = hipStreamCreateWithPriority(&ss->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ss->stepped, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ss->refilled[0], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ss->refilled[1], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            delete ss;
+            return nullptr;
+        }
+        per_device[dev] = ss;
+    }
+    return per_device[dev];
+}
+
 int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
     if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0)
         return fail(BPP_E_BADARG, "bpp_stream: need num_envs > 0, depth >= 4, pool_len >= 2");
     if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi))
         return fail(BPP_E_BADARG, "bpp_stream: bin / bounds the reference generator cannot cut");
-    if (((uintptr_t)s->ring & 3u) || ((uintptr_t)s->work & 7u)) return fail(BPP_E_BADARG, "bpp_stream: misaligned buffer");
+    if (((uintptr_t)s->ring & 3u) || ((uintptr_t)s->work & 15u) || ((uintptr_t)s->mt & 15u))
+        return fail(BPP_E_BADARG, "bpp_stream: misaligned buffer");
     return 0;
+}
+
+// The fast pipeline needs rows that hold every possible sequence (the cut kernel writes unsorted entries in place),
+// rows the sort kernel can stage in LDS, and a cut-kernel workgroup that fits the LDS of a CU.
+struct StreamPlan {
+    bool fast;
+    int maxn, cap, nsp, nslots;
+    size_t off_jobs, off_target, off_rows, off_spill, fast_bytes, legacy_bytes, cut_lds, sort_lds;
+};
+StreamPlan plan_stream(const bpp_stream *s) {
+    StreamPlan p{};
+    const size_t E = (size_t)s->num_envs;
+    p.maxn = s->W * s->L * s->H / (s->bound_lo * s->bound_lo * s->bound_lo);   // most boxes a sequence can have
+    p.cap = stream_pend_cap(p.maxn);
+    p.nsp = p.maxn > p.cap ? p.maxn - p.cap : 0;
+    p.nslots = (int)((E + 63) / 64 + 3) * 64;
+    p.off_jobs = 64;
+    p.off_target = (p.off_jobs + 3 * E * 4 + 15) & ~(size_t)15;
+    p.off_rows = (p.off_target + E * 4 + 15) & ~(size_t)15;
+    p.off_spill = (p.off_rows + (size_t)s->depth * E * 8 + 15) & ~(size_t)15;
+    p.fast_bytes = p.off_spill + (size_t)2 * p.nsp * p.nslots * 4;
+    p.legacy_bytes = (size_t)stream_work_entries(s->W, s->L, s->H, s->bound_lo) * E * 8;
+    p.cut_lds = ((size_t)(2 * p.cap + kRngWin) * 64 + kTwistWords) * 4;
+    p.sort_lds = (size_t)4 * (s->pool_len + 256) * 4;
+    p.fast = s->pool_len - 1 >= p.maxn && s->pool_len <= kSortMaxT && p.cut_lds <= 64 * 1024 && p.sort_lds <= 64 * 1024;
+    return p;
 }
 }  // namespace
 
 extern "C" {
+
+int bpp_stream_sizes(const bpp_stream *s, int64_t out[2]) {
+    if (!s || !out) return fail(BPP_E_BADARG, "bpp_stream_sizes: NULL pointer");
+    if (s->num_envs <= 0 || s->depth < 4 || !bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi))
+        return fail(BPP_E_BADARG, "bpp_stream_sizes: fill in num_envs, depth, pool_len, the bin and the bounds first");
+    const StreamPlan p = plan_stream(s);
+    out[0] = (int64_t)kMtRec * s->num_envs;
+    out[1] = (int64_t)(p.fast_bytes > p.legacy_bytes ? p.fast_bytes : p.legacy_bytes);
+    return 0;
+}
 
 int bpp_stream_init(const bpp_stream *s, void *stream) {
     int rc = check_stream(s);
@@ -2264,9 +2331,25 @@ int bpp_stream_init(const bpp_stream *s, void *stream) {
 int bpp_stream_refill(const bpp_stream *s, void *stream) {
     int rc = check_stream(s);
     if (rc) return rc;
-    hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + kStreamLanes - 1) / kStreamLanes), dim3(kStreamLanes),
-                       (size_t)kStreamLdsWords * kStreamLanes * 4, (hipStream_t)stream, *s);
-    hipError_t e = hipGetLastError();
+    const StreamPlan p = plan_stream(s);
+    hipStream_t st = (hipStream_t)stream;
+    if (!p.fast || current_knobs().stream_legacy) {
+        hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + kStreamLanes - 1) / kStreamLanes), dim3(kStreamLanes),
+                           (size_t)kStreamLdsWords * kStreamLanes * 4, st, *s);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+    }
+    unsigned char *base = (unsigned char *)s->work;
+    const StreamWork w{(int32_t *)base, (int32_t *)(base + p.off_jobs), (int32_t *)(base + p.off_target), (int64_t *)(base + p.off_rows),
+                       (uint32_t *)(base + p.off_spill), p.cap, p.nsp, p.nslots, p.maxn};
+    hipError_t e = hipMemsetAsync(base, 0, 64, st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    const int E = s->num_envs;
+    hipLaunchKernelGGL(stream_scan_kernel, dim3((E + 255) / 256), dim3(256), 0, st, *s, w);
+    hipLaunchKernelGGL(stream_cut_kernel, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+    const int64_t most = ((int64_t)E * s->depth + 3) / 4;
+    hipLaunchKernelGGL(stream_sort_kernel, dim3((unsigned)(most < 2048 ? most : 2048)), dim3(256), p.sort_lds, st, *s, w);
+    e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
 
@@ -2276,10 +2359,31 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
     if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - 3)
         return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");
     int rc = 0;
-    for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every) {
+    // With depth >= 2 R + 3 rows per bin the refill that follows a chunk of R lock-steps may run BESIDE the next chunk
+    // (it only rewrites rows of finished episodes; a bin advances by at most R episodes per chunk and a step reads two
+    // rows ahead): it goes to a side stream, and a chunk starts once the refill issued two chunks earlier is complete.
+    SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + 3) ? side_stream() : nullptr;
+    hipStream_t main = (hipStream_t)stream;
+    int32_t chunk = 0;
+    for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every, ++chunk) {
         const int32_t n = nsteps - done < refill_every ? nsteps - done : refill_every;
+        if (side && chunk >= 2) (void)hipStreamWaitEvent(main, side->refilled[chunk & 1], 0);
         rc = bpp_rollout_uniform(b, out, actions, seed, step0 + (uint64_t)done, n, stream);
-        if (rc == 0) rc = bpp_stream_refill(s, stream);
+        if (rc) break;
+        if (!side) {
+            rc = bpp_stream_refill(s, stream);
+            continue;
+        }
+        (void)hipEventRecord(side->stepped, main);
+        (void)hipStreamWaitEvent(side->stream, side->stepped, 0);
+        rc = bpp_stream_refill(s, side->stream);
+        (void)hipEventRecord(side->refilled[chunk & 1], side->stream);
+    }
+    if (side) {     // everything enqueued on `stream` after this call sees the refilled ring
+        if (chunk >= 2) (void)hipStreamWaitEvent(main, side->refilled[chunk & 1], 0);
+        if (chunk >= 1) (void)hipStreamWaitEvent(main, side->refilled[(chunk - 1) & 1], 0);
+        hipError_t e = hipGetLastError();
+        if (rc == 0 && e != hipSuccess) rc = hip_fail(e, "side-stream refill");
     }
     return rc;
 }

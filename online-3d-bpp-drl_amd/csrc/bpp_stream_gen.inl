@@ -182,16 +182,353 @@ struct ArrayVals {
     void set(int i, uint32_t v) { base[i] = v; }
 };
 
-constexpr int kStreamMtWords = 625;   // 624 state words + the index
+// ---- per-bin generator record in bpp_stream.mt (opaque to callers; bpp_stream_sizes gives the size): kMtRec words per
+// bin, contiguous -- [0, 624) the MT19937 state, [624] index of the next unused state word (0..624), [625] number of
+// tempered outputs carried over from the last refill, [626, 658) those outputs (the fast cut kernel hands out
+// outputs from a 32-word window and keeps what it did not use).
+constexpr int kMtRec = 672;
+constexpr int kMtIdx = 624, kMtLeftN = 625, kMtLeft = 626;
 
 __host__ __device__ inline int stream_work_entries(int W, int L, int H, int lo) { return W * L * H / (lo * lo * lo) + 8; }
 
-// ---- device side: one lane per bin, the hot state in LDS -------------------------------------------------------------
-// Every access of the list walk is a dependent round trip, so where the lists live decides the kernel's speed: the
-// first kStreamPendCap pending boxes and kStreamValCap cut boxes of a lane sit in LDS (word w of lane l at
-// lds[w * 64 + l]: conflict-free), anything beyond -- rare -- spills to the caller's global `work` array.  The
-// generator draws from a 32-word LDS buffer of tempered outputs refilled with 32 independent loads, and twists its
-// state in chunks of 16 words (17 + 16 independent loads, then 16 stores) instead of word by word.
+__host__ __device__ inline uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// ======================================================================================================================
+// Refill, fast pipeline: three kernels per bpp_stream_refill.
+//   scan  one lane per bin: which bins have used up rows since the last refill (jobs, bucketed by the number of
+//         sequences they need so that a wave's lanes finish together) and which ring rows will be rewritten;
+//   cut   one lane per job, single-wave workgroups.  The list walk of mdCreator.py:117-135 is run as a state
+//         machine that consumes EXACTLY ONE 32-bit generator output per iteration (a rejected randbelow draw, a
+//         failed split attempt and a split are all one iteration), so the lanes of a wave stay converged, read
+//         their outputs from the same slot of a 32-word LDS window, and refill that window together.  The pending
+//         boxes live in two LDS lists per lane (this pass / survivors for the next pass: no shifting, no
+//         compaction); a generator that runs off the end of its state is twisted by the whole wave (coalesced,
+//         through LDS).  Cut boxes go straight into the ring row, unsorted, with their base height as sort key;
+//   sort  one wave per rewritten row: stable counting sort by base height (depart_box, :137-138), key stripped,
+//         terminator padding.
+// Same draws in the same order as cut2_generate above (tests/test_stream_supply.py runs both against the oracle's
+// generator and Python's random module).
+// ======================================================================================================================
+struct StreamWork {        // views into bpp_stream.work (see stream_work_layout)
+    int32_t *hdr;          // [16]: jobs in bucket 0..2, rows to sort
+    int32_t *jobs;         // [3][E]: local bin ids needing 1 / 2 / >= 3 sequences
+    int32_t *target;       // [E]: gen_next every bin is brought to (the scan's reading of episode + depth: the step
+                           //      kernels may be running beside the refill, the three kernels must agree on one value)
+    int64_t *rows;         // [D * E]: bin | episode << 32 of every row rewritten by this refill
+    uint32_t *spill;       // [2 * nsp][nslots]: pending boxes beyond the LDS lists (rare)
+    int32_t cap, nsp, nslots, maxn;
+};
+constexpr int kRngWin = 32;            // generator outputs per window
+constexpr int kTwistWords = 640;       // LDS scratch of the wave-wide twist (624 used)
+constexpr int kSortMaxT = 2048;        // longest row the sort kernel stages in LDS
+
+// LDS entries per pending list for sequences of at most maxn boxes.  Measured peaks: 10^3 bins 10 on average, above 16
+// in 0.5 % of the sequences, 21 at most in 3000; 20^3 bins 68.  Longer lists continue in global memory.  Small lists
+// keep the workgroup below the LDS of one step-kernel workgroup, so that it finds room on a CU the step kernel is using.
+__host__ inline int stream_pend_cap(int maxn) {
+    int c = (maxn / 18 + 8 + 7) / 8 * 8;
+    c = c < 16 ? 16 : (c > 80 ? 80 : c);
+    return c < maxn ? c : maxn;
+}
+
+__global__ __launch_bounds__(256) void stream_scan_kernel(bpp_stream s, StreamWork w) {
+    const int e = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int E = s.num_envs, D = s.depth;
+    int need = 0, g0 = 0;
+    if (e < E) {
+        g0 = s.gen_next[e];
+        need = s.state[e].episode + D - g0;
+        need = need < 0 ? 0 : need;
+        w.target[e] = g0 + need;
+    }
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int bucket = need >= 3 ? 2 : need - 1;
+    for (int b = 0; b < 3; ++b) {
+        const uint64_t m = __ballot(bucket == b);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __ffsll((unsigned long long)m) - 1) base = atomicAdd(&w.hdr[b], __popcll(m));
+        base = __shfl(base, __ffsll((unsigned long long)m) - 1, 64);
+        if (bucket == b) w.jobs[(size_t)b * E + base + __popcll(m & below)] = e;
+    }
+    // rows: only the last D sequences of a bin survive in the ring
+    const int nr = need < D ? need : D;
+    int incl = nr;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&w.hdr[3], total);
+    base = __shfl(base, 0, 64);
+    const int first = g0 + need - nr;
+    for (int k = 0; k < nr; ++k)
+        w.rows[base + incl - nr + k] = (int64_t)(uint32_t)e | ((int64_t)(first + k) << 32);
+}
+
+// the pending lists of one lane: list r, entry i
+struct PendLists {
+    uint32_t *lds;      // &lds[lane]: word w of this lane at lds[w * 64]
+    uint32_t *spill;    // &spill[slot]: entry k of list r beyond the LDS part at spill[(r * nsp + k) * nslots]
+    int cap, nsp;
+    size_t nslots;
+    __device__ __forceinline__ uint32_t get(int r, int i) const {
+        return i < cap ? lds[(r * cap + i) * 64] : spill[(size_t)(r * nsp + i - cap) * nslots];
+    }
+    __device__ __forceinline__ void set(int r, int i, uint32_t v) const {
+        if (i < cap) lds[(r * cap + i) * 64] = v;
+        else spill[(size_t)(r * nsp + i - cap) * nslots] = v;
+    }
+};
+
+// The whole wave regenerates the 624 state words of one bin (rec: global, tw: LDS scratch).  Word k needs the OLD
+// words k and k+1 and word k+397 (old for k < 227, else the NEW word k-227); walking k in rounds of 64 consecutive
+// words with all reads of a round before its writes gives every lane exactly those values (word 623 reads the new
+// word 0, as the serial loop does).
+__device__ __forceinline__ void stream_wave_twist(uint32_t *rec, uint32_t *tw, int lane) {
+    for (int k = lane; k < 624; k += 64) tw[k] = rec[k];
+    wave_sync();
+    for (int k0 = 0; k0 < 624; k0 += 64) {
+        const int k = k0 + lane;
+        uint32_t a = 0, b = 0, c = 0;
+        if (k < 624) {
+            a = tw[k];
+            b = tw[k + 1 < 624 ? k + 1 : 0];
+            c = tw[k + 397 < 624 ? k + 397 : k - 227];
+        }
+        wave_sync();
+        if (k < 624) {
+            const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            tw[k] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wave_sync();
+    }
+    for (int k = lane; k < 624; k += 64) rec[k] = tw[k];
+}
+
+__global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds = (uint32_t *)smem;
+    const int lane = threadIdx.x;
+    const int E = s.num_envs, T = s.pool_len, D = s.depth;
+    const uint32_t lo = (uint32_t)s.bound_lo, hi = (uint32_t)s.bound_hi;
+    // wave -> (bucket, position): the longest jobs are dispatched first
+    const int n3 = w.hdr[2], n2 = w.hdr[1], n1 = w.hdr[0];
+    const int w3 = (n3 + 63) >> 6, w2 = (n2 + 63) >> 6, w1 = (n1 + 63) >> 6;
+    int b = blockIdx.x, n, bucket;
+    if (b < w3) n = n3, bucket = 2;
+    else if (b < w3 + w2) b -= w3, n = n2, bucket = 1;
+    else if (b < w3 + w2 + w1) b -= w3 + w2, n = n1, bucket = 0;
+    else return;
+    const int j = b * 64 + lane;
+    const bool job = j < n;
+    const int e = job ? w.jobs[(size_t)bucket * E + j] : 0;
+    uint32_t *rec = s.mt + (size_t)e * kMtRec;
+    uint32_t *buf = lds + (size_t)(2 * w.cap) * 64 + lane;          // output window: slot q at buf[q * 64]
+    uint32_t *tw = lds + (size_t)(2 * w.cap + kRngWin) * 64;        // twist scratch of the wave
+    const PendLists pend{lds + lane, w.spill + (size_t)blockIdx.x * 64 + lane, w.cap, w.nsp, (size_t)w.nslots};
+
+    int idx = 0, g = 0, need = 0, carried = 0;
+    if (job) {
+        idx = (int)rec[kMtIdx];
+        carried = (int)rec[kMtLeftN];
+        g = s.gen_next[e];
+        need = w.target[e] - g;
+        for (int q = 0; q < kRngWin; ++q)
+            if (q < carried) buf[q * 64] = rec[kMtLeft + q];
+    }
+    bool active = job && need > 0;
+    const bool ran = active;
+
+    // append kRngWin - from fresh outputs to the windows of the lanes in `want` (slots from .. 31)
+    auto fill = [&](bool want, int from) {
+#pragma unroll 8
+        for (int q = 0; q < kRngWin; ++q) {
+            const int k = idx + q - from;
+            if (want && q >= from && k < 624) buf[q * 64] = mt_temper(rec[k]);
+        }
+        uint64_t m = __ballot(want && idx + kRngWin - from > 624);
+        while (m) {                                   // wave-uniform: one bin at a time, all lanes help
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int el = (int)__builtin_amdgcn_readlane(e, l), il = (int)__builtin_amdgcn_readlane(idx, l);
+            const int fl = (int)__builtin_amdgcn_readlane(from, l);
+            wave_sync();
+            stream_wave_twist(s.mt + (size_t)el * kMtRec, tw, lane);
+            wave_sync();
+            const int k = il + lane - fl - 624;       // slot `lane` of bin l's window takes the new word k
+            if (lane < kRngWin && lane >= fl && k >= 0) lds[(size_t)(2 * w.cap + lane) * 64 + l] = mt_temper(tw[k]);
+            wave_sync();
+        }
+        if (want) {
+            idx += kRngWin - from;
+            if (idx > 624) idx -= 624;
+        }
+    };
+    fill(active, carried);
+
+    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    int i = 0, tail_a = 1, tail_b = 0, side = 0, st = 0, f = 0, nv = 0, endpos = 0;
+    uint32_t box = whole, v = 0;
+    uint32_t *row = (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T;
+    if (active) pend.set(0, 0, whole);
+    int pos = 0;
+    while (__ballot(active)) {
+        if (pos == kRngWin) {
+            fill(active, 0);
+            pos = 0;
+        }
+        if (active) {
+            const uint32_t u = buf[pos * 64];
+            const uint32_t bx = box & 255u, by = (box >> 8) & 255u, bz = (box >> 16) & 255u;
+            const bool fx = bx > hi, fy = by > hi, fz = bz > hi;            // mdCreator.py:60-66
+            const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
+            int outcome = 0;                                                  // 1: the attempt failed, 2: split
+            uint32_t r = 0;
+            if (st == 0) {                                                    // random.choice(flags), :68
+                const uint32_t x = u >> (nf == 1u ? 31 : 30);                // getrandbits(bit_length(nf))
+                if (x < nf) {
+                    f = x == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x == 1u ? ((fx && fy) ? 1 : 2) : 2);
+                    v = f == 0 ? bx : (f == 1 ? by : bz);
+                    if (f == 0 ? v <= lo : v < lo) outcome = 1;               // :71, :81, :91
+                    else st = 1;
+                }
+            } else {                                                          // random.randint(1, v), :73 / :83 / :93
+                const uint32_t x = u >> __clz((int)v);                        // getrandbits(bit_length(v))
+                if (x < v) {
+                    r = x + 1u;
+                    outcome = (r < lo || v - r < lo) ? 1 : 2;                 // :74, :84, :94
+                }
+            }
+            if (outcome == 1) {
+                pend.set(side ^ 1, tail_b++, box);                            // stays in invalid_box for the next pass
+            } else if (outcome == 2) {
+                const uint32_t sh = 8u * (uint32_t)f, p1 = f == 2 ? v - r : r, p2 = v - p1;
+                const uint32_t rest = box & ~(255u << sh);
+                const uint32_t c1 = rest | (p1 << sh);
+                const uint32_t c2 = (rest | (p2 << sh)) + (f == 2 ? p1 << 24 : 0u);   // :97-98: the upper part starts at high - r
+                // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
+                if (nf == 1u && p1 <= hi) row[nv++] = c1;
+                else pend.set(side, tail_a++, c1);                            // appended: visited later in this pass
+                if (nf == 1u && p2 <= hi) row[nv++] = c2;
+                else pend.set(side, tail_a++, c2);
+            }
+            if (outcome) {
+                ++i;
+                if (outcome == 2 && i < tail_a) {     // the removal slid the next box under the iterator: not visited in this pass
+                    pend.set(side ^ 1, tail_b++, pend.get(side, i));
+                    ++i;
+                }
+                bool finished = false;
+                if (i >= tail_a) {                    // end of the `for`: next pass over the survivors, or done
+                    finished = tail_b == 0;
+                    side ^= 1;
+                    tail_a = tail_b;
+                    tail_b = 0;
+                    i = 0;
+                }
+                st = 0;
+                if (!finished) {
+                    box = pend.get(side, i);
+                } else {
+                    row[T - 1] = (uint32_t)nv;        // length for the sort kernel (which restores the terminator)
+                    ++g;
+                    if (--need > 0) {
+                        row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+                        pend.set(side, 0, whole);
+                        tail_a = 1;
+                        nv = 0;
+                        box = whole;
+                    } else {
+                        active = false;
+                        endpos = pos + 1;
+                    }
+                }
+            }
+        }
+        ++pos;
+    }
+    if (ran) {                                        // keep the outputs of the window that were not used
+        rec[kMtIdx] = (uint32_t)idx;
+        rec[kMtLeftN] = (uint32_t)(kRngWin - endpos);
+        for (int q = 0; q < kRngWin; ++q)
+            if (q >= endpos) rec[kMtLeft + q - endpos] = buf[q * 64];
+        s.gen_next[e] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWork w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = s.num_envs, T = s.pool_len, D = s.depth;
+    uint32_t *ent = (uint32_t *)smem + (size_t)wave * (T + 256);
+    int *lvl = (int *)(ent + T);                      // per base height: count, then first free position
+    const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int nrows = w.hdr[3];
+    for (int q = blockIdx.x * 4 + wave; q < nrows; q += gridDim.x * 4) {     // wave-uniform
+        const int64_t id = w.rows[q];
+        const int e = (int)(uint32_t)id, g = (int)(id >> 32);
+        uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+        const int nv = (int)row[T - 1];
+        wave_sync();
+        for (int k = lane; k < 256; k += 64) lvl[k] = 0;
+        for (int k = lane; k < nv; k += 64) ent[k] = row[k];
+        wave_sync();
+        for (int k = lane; k < nv; k += 64) atomicAdd(&lvl[ent[k] >> 24], 1);
+        wave_sync();
+        {   // exclusive prefix over the 256 levels, four per lane
+            const int c0 = lvl[4 * lane], c1 = lvl[4 * lane + 1], c2 = lvl[4 * lane + 2], c3 = lvl[4 * lane + 3];
+            int incl = c0 + c1 + c2 + c3;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            const int ex = incl - (c0 + c1 + c2 + c3);
+            wave_sync();
+            lvl[4 * lane] = ex;
+            lvl[4 * lane + 1] = ex + c0;
+            lvl[4 * lane + 2] = ex + c0 + c1;
+            lvl[4 * lane + 3] = ex + c0 + c1 + c2;
+        }
+        wave_sync();
+        for (int k0 = 0; k0 < nv; k0 += 64) {         // stable: chunks in order, lanes in order within a level
+            const int k = k0 + lane;
+            const bool valid = k < nv;
+            const uint32_t val = valid ? ent[k] : 0u;
+            const uint32_t key = val >> 24;
+            int dest = 0;
+            uint64_t todo = __ballot(valid);
+            while (todo) {
+                const int l0 = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t lv = __builtin_amdgcn_readlane(key, l0);
+                const uint64_t m = __ballot(valid && key == lv);
+                const int first = lvl[lv];
+                if (valid && key == lv) dest = first + __popcll(m & below);
+                wave_sync();
+                if (lane == l0) lvl[lv] = first + __popcll(m);
+                wave_sync();
+                todo &= ~m;
+            }
+            if (valid) row[dest] = val & 0x00ffffffu;
+        }
+        for (int k = nv + lane; k < T; k += 64) row[k] = term;
+        wave_sync();
+    }
+}
+
+// ======================================================================================================================
+// Refill, plain version: one lane per bin runs cut2_generate as it stands (any geometry, any row length; knob
+// stream_legacy).  Lists and a 32-word output buffer in LDS, beyond that the caller's `work` array.
+// ======================================================================================================================
 constexpr int kStreamLanes = 64;        // threads per workgroup of the refill kernel
 constexpr int kStreamPendCap = 48;
 constexpr int kStreamValCap = 64;
@@ -226,33 +563,34 @@ struct LdsVals {
     }
 };
 
-// CPython's random.Random for one bin: state words in global memory (word i of bin e at mt[i * E + e]), tempered outputs
-// handed out from an LDS buffer.
+// CPython's random.Random for one bin: the bin's record in global memory, tempered outputs handed out from an LDS
+// buffer (first the outputs a fast refill left over, then fresh ones; a refill of the buffer never crosses a twist, so
+// unused outputs are returned by stepping the index back).
 struct BufferedMT {
-    uint32_t *mt;       // &mt[e]
-    size_t stride;      // E
+    uint32_t *mt;       // the bin's record
     uint32_t *buf;      // this lane's column of the output buffer
     int idx;            // next state word to temper (0..624)
     int have, pos;      // buffered outputs, next one to hand out
+    bool carried;       // the buffer holds carried-over outputs (not re-derivable from idx)
     __device__ void twist() {
         for (int k0 = 0; k0 < 624; k0 += 16) {
             uint32_t cur[17], far[16];
 #pragma unroll
             for (int q = 0; q < 17; ++q) {
                 const int k = k0 + q;
-                cur[q] = mt[(size_t)(k < 624 ? k : 0) * stride];
+                cur[q] = mt[k < 624 ? k : 0];
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k = k0 + q;
-                far[q] = k < 624 ? mt[(size_t)(k + 397 < 624 ? k + 397 : k - 227) * stride] : 0u;
+                far[q] = k < 624 ? mt[k + 397 < 624 ? k + 397 : k - 227] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k = k0 + q;
                 if (k < 624) {
                     const uint32_t y = (cur[q] & 0x80000000u) | (cur[q + 1] & 0x7fffffffu);
-                    mt[(size_t)k * stride] = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    mt[k] = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
                 }
             }
         }
@@ -260,20 +598,15 @@ struct BufferedMT {
     }
     __device__ uint32_t u32() {
         if (pos >= have) {
+            carried = false;
             if (idx >= 624) twist();
             const int n = 624 - idx < kStreamRngBuf ? 624 - idx : kStreamRngBuf;
             uint32_t y[kStreamRngBuf];
 #pragma unroll
-            for (int q = 0; q < kStreamRngBuf; ++q) y[q] = q < n ? mt[(size_t)(idx + q) * stride] : 0u;
+            for (int q = 0; q < kStreamRngBuf; ++q) y[q] = q < n ? mt[idx + q] : 0u;
 #pragma unroll
-            for (int q = 0; q < kStreamRngBuf; ++q) {
-                uint32_t v = y[q];
-                v ^= v >> 11;
-                v ^= (v << 7) & 0x9d2c5680u;
-                v ^= (v << 15) & 0xefc60000u;
-                v ^= v >> 18;
-                if (q < n) buf[q * kStreamLanes] = v;
-            }
+            for (int q = 0; q < kStreamRngBuf; ++q)
+                if (q < n) buf[q * kStreamLanes] = mt_temper(y[q]);
             idx += n;
             have = n;
             pos = 0;
@@ -286,9 +619,11 @@ struct BufferedMT {
 __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= s.num_envs) return;
-    StridedMT rng{s.mt + e, (size_t)s.num_envs, 624};
+    uint32_t *rec = s.mt + (size_t)e * kMtRec;
+    StridedMT rng{rec, 1, 624};
     rng.seed(s.seed0 + (uint64_t)(s.env_id_base + e));
-    s.mt[(size_t)624 * s.num_envs + e] = (uint32_t)rng.idx;
+    rec[kMtIdx] = (uint32_t)rng.idx;
+    rec[kMtLeftN] = 0u;
     s.gen_next[e] = 0;
 }
 
@@ -304,8 +639,10 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
     const int cur = s.state[e].episode;
     int g = s.gen_next[e];
     if (g >= cur + D) return;
-    BufferedMT rng{s.mt + e, (size_t)E, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
-                   (int)s.mt[(size_t)624 * E + e], 0, 0};
+    uint32_t *rec = s.mt + (size_t)e * kMtRec;
+    BufferedMT rng{rec, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane, (int)rec[kMtIdx], (int)rec[kMtLeftN], 0,
+                   true};
+    for (int q = 0; q < rng.have; ++q) rng.buf[q * kStreamLanes] = rec[kMtLeft + q];
     LdsWork work{lds + lane, (CutBox *)s.work + e, (size_t)E};
     const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
     int over = 0;
@@ -319,8 +656,15 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
         for (int t = nw; t < T; ++t) row[t] = term;                        // pad with the terminator (last entry always)
         ++g;
     }
-    // buffered but unused outputs are handed out again next time: remember the index of the next unused state word
-    s.mt[(size_t)624 * E + e] = (uint32_t)(rng.idx - (rng.have - rng.pos));
+    // unused outputs: carried-over ones stay in the record, fresh ones are returned by stepping the index back
+    const int left = rng.have - rng.pos;
+    if (rng.carried) {
+        rec[kMtLeftN] = (uint32_t)left;
+        for (int q = 0; q < left; ++q) rec[kMtLeft + q] = rng.buf[(rng.pos + q) * kStreamLanes];
+    } else {
+        rec[kMtLeftN] = 0u;
+        rec[kMtIdx] = (uint32_t)(rng.idx - left);
+    }
     s.gen_next[e] = g;
     if (over && s.overflow) atomicAdd(s.overflow, over);
 }

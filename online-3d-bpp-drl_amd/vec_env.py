@@ -182,8 +182,11 @@ class BppVecEnv(object):
                 if not 1 <= self.refill_every <= depth - 3:
                     raise ValueError("refill_every must be in 1 .. depth - 3")
                 self.pool = torch.zeros((depth * self.E, pool_len, 4), dtype=torch.uint8, device=dev)   # the ring
-                self._mt = torch.zeros((625, self.E), dtype=torch.int32, device=dev)
-                self._work = torch.zeros((self.W * self.L * self.H // lo ** 3 + 8, self.E, 2), dtype=torch.int32, device=dev)
+                sizes = (ctypes.c_int64 * 2)()      # the two opaque buffers of a bpp_stream: generator records, scratch
+                probe = _lib.Stream(self.E, depth, pool_len, self.W, self.L, self.H, lo, hi, 0, 0, None, None, None, None, None, None)
+                _lib.check(self.lib.bpp_stream_sizes(ctypes.byref(probe), sizes))
+                self._mt = torch.zeros((self.E, int(sizes[0]) // self.E), dtype=torch.int32, device=dev)
+                self._work = torch.zeros(((int(sizes[1]) + 15) // 16, 4), dtype=torch.int32, device=dev)
                 self.gen_next = torch.zeros((self.E,), dtype=torch.int32, device=dev)
                 self.stream_overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
                 pool_rows, pool_mode = depth * self.E, _lib.POOL_RING
@@ -450,8 +453,7 @@ class BppVecEnv(object):
         if self._stream is not None:       # the copy continues the source's item stream: ring rows + generator state
             ring = self.pool.view(self.stream_spec["depth"], self.E, -1)
             ring[:, dst] = ring[:, src]
-            self._mt[:, dst] = self._mt[:, src]
-            self._work[:, dst] = self._work[:, src]
+            self._mt[dst] = self._mt[src]
             self.gen_next[dst] = self.gen_next[src]
 
     def preview(self, k):

@@ -31,7 +31,7 @@ static int fail(int code, const char *msg) {
 int bpp_abi_version(void) { return BPP_ABI_VERSION; }
 const char *bpp_last_error(void) { return g_err; }
 /* the oracle has no launch shapes: the knobs are accepted and remembered, nothing depends on them */
-static bpp_knobs g_knobs = {0, 0, 1, 0, 0, 0, 0, {0}};
+static bpp_knobs g_knobs = {0, 0, 1, 0, 0, 0, 0, 0, 1, {0, 0, 0}};
 int bpp_get_knobs(bpp_knobs *out) {
     if (!out) return fail(BPP_E_BADARG, "bpp_get_knobs: NULL");
     *out = g_knobs;
@@ -600,6 +600,14 @@ static int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
     if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0) return fail(BPP_E_BADARG, "bpp_stream: bad size");
     if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi)) return fail(BPP_E_BADARG, "bpp_stream: bad bounds");
+    return 0;
+}
+
+int bpp_stream_sizes(const bpp_stream *s, int64_t out[2]) {
+    if (!s || !out) return fail(BPP_E_BADARG, "bpp_stream_sizes: NULL pointer");
+    if (s->num_envs <= 0) return fail(BPP_E_BADARG, "bpp_stream_sizes: bad size");
+    out[0] = (int64_t)(sizeof(bpp_mt) / 4) * s->num_envs;   /* one bpp_mt per bin */
+    out[1] = 16;                                            /* no scratch needed on the host */
     return 0;
 }
 

@@ -46,12 +46,13 @@ class StepOut(ctypes.Structure):
 class Knobs(ctypes.Structure):
     _fields_ = [("bins_per_wave", ctypes.c_int32), ("waves_per_group", ctypes.c_int32), ("xcd_remap", ctypes.c_int32),
                 ("force_generic", ctypes.c_int32), ("ablate", ctypes.c_int32), ("legacy_fast", ctypes.c_int32),
-                ("tile_groups", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("tile_groups", ctypes.c_int32), ("stream_legacy", ctypes.c_int32), ("stream_overlap", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 3)]
 
 
-def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=0, tile_groups=0):
+def set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=0, tile_groups=0, stream_legacy=0, stream_overlap=1):
     """bpp_set_knobs of whatever library this front-end is bound to (meaningful for the emulated product)."""
-    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0, int(legacy_fast), int(tile_groups))
+    k = Knobs(int(bins_per_wave), int(waves_per_group), int(xcd_remap), int(force_generic), 0, int(legacy_fast), int(tile_groups), int(stream_legacy), int(stream_overlap))
     _check(lib().bpp_set_knobs(ctypes.byref(k)))
 
 
@@ -97,6 +98,7 @@ def lib():
                                                                                      ctypes.c_uint64, ctypes.c_int32]
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
+        L.bpp_stream_sizes.argtypes = [ctypes.POINTER(Stream), ctypes.POINTER(ctypes.c_int64)]
         L.bpp_stream_init.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
@@ -114,6 +116,12 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _aligned_zeros(nbytes, align=64):
+    raw = np.zeros(nbytes + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + nbytes]
 
 
 class OracleEnv(object):
@@ -149,13 +157,16 @@ class OracleEnv(object):
                         1 if stream is not None else 0, 0)
         if stream is not None:
             E = self.E
-            self._mt = np.zeros((625, E), np.uint32)
-            self._work = np.zeros((self.W * self.L * self.H // lo ** 3 + 8, E, 2), np.uint32)
             self.gen_next = np.zeros(E, np.int32)
             self.overflow = np.zeros(1, np.int32)
             self.stream = Stream(E, D, T, self.W, self.L, self.H, lo, hi, int(env_id_base), int(stream.get("seed", 0)),
-                                 _p(self.pool).value, _p(self._mt).value, _p(self._work).value, _p(self.gen_next).value,
+                                 _p(self.pool).value, None, None, _p(self.gen_next).value,
                                  _p(self.state).value, _p(self.overflow).value)
+            sizes = (ctypes.c_int64 * 2)()          # the two opaque buffers are sized by the library in use
+            _check(lib().bpp_stream_sizes(ctypes.byref(self.stream), sizes))
+            self._mt = _aligned_zeros(int(sizes[0]) * 4)
+            self._work = _aligned_zeros(int(sizes[1]))
+            self.stream.mt, self.stream.work = _p(self._mt).value, _p(self._work).value
             self.refill_every = int(stream.get("refill_every", max(1, D - 3)))
             self._since_refill = 0
             _check(lib().bpp_stream_init(ctypes.byref(self.stream), None))

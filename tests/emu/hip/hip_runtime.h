@@ -49,6 +49,28 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return hipSuccess;
+}
+// streams and events: everything runs at once and in order here
+typedef void *hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) {
+    *least = 0;
+    *greatest = 0;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) {
+    *s = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+    *e = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) {
     *d = 0;
     return hipSuccess;
