@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--stream", action="store_true",
                     help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
                          "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
+    ap.add_argument("--stream-depth", type=int, default=16, help="--stream: ring rows per bin")
+    ap.add_argument("--stream-refill", type=int, default=6,
+                    help="--stream: lock-steps between refills (with depth >= 2 * refill + 3 the refills run beside the lock-steps)")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: enough "
                          "repetitions for >= 100 ms of timed work, at most 25, so that a small --steps is not a 1 ms sample)")
@@ -207,7 +210,7 @@ def main():
 
     env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=None if args.stream else pool, device=device,
                             env_id_base=rank * E, env_id_total=world * E,
-                            stream=dict(bound=(2, 5), seed=0, depth=8, refill_every=5) if args.stream else None)
+                            stream=dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill) if args.stream else None)
     stats = bpp_amd.EpisodeStats(device)
     actions = torch.empty(E, dtype=torch.int64, device=device)
     env.reset()
@@ -309,7 +312,10 @@ def main():
             "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
                                    % (size + (" + rotation" if args.rotation else "", E)),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
-                       "pool_source": ("device stream: random.Random(g) per bin, refill every 5 lock-steps (bpp_stream)" if args.stream
+                       "pool_source": ("device stream: random.Random(g) per bin, ring of %d rows, refill every %d lock-steps%s (bpp_stream)"
+                                       % (args.stream_depth, args.stream_refill,
+                                          " beside the lock-steps" if args.stream_depth >= 2 * args.stream_refill + 3
+                                          and bpp_amd._lib.get_knobs()["stream_overlap"] else "") if args.stream
                                        else args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)"),
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s%s)"
                                    % (world, "RCCL" if backend == "nccl" else backend,

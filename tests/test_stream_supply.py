@@ -85,6 +85,79 @@ def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native):
     assert int(rst["episode"].max()) >= 1
 
 
+def knob_check(front, oracle, set_knobs, size, E, depth, steps, pattern, refill=None, seed=7, base=100, fail=0.2):
+    """Fast pipeline (scan / cut / sort) and the one-lane-per-bin kernel are interchangeable refill by refill: `pattern(t)`
+    chooses which one serves lock-step t.  Everything a step returns and, at the end, the whole ring must equal the
+    oracle's (its generator is the plain-C one of include/bpp_gen.inl)."""
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill or max(1, depth - 3))
+    set_knobs(stream_legacy=pattern(0))
+    try:
+        env = front(size, E, base, spec)
+        ref = oracle.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E + 3, stream=spec)
+        (obs, mask), (robs, rmask) = env.reset(), ref.reset()
+        np.testing.assert_array_equal(obs, robs)
+        rng = np.random.RandomState(3)
+        for t in range(steps):
+            set_knobs(stream_legacy=pattern(t + 1))
+            a = oracle.sample_feasible(rmask, 5, t, env_id_base=base)
+            a[rng.rand(E) < (fail if E >= 8 else 0.8)] = -1   # failures make bins race through their episodes
+            r, o = env.step(a), ref.step(a)
+            for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg="%s t=%d" % (k, t))
+            rmask = o["mask"]
+        np.testing.assert_array_equal(env.ring(), ref.pool)
+        np.testing.assert_array_equal(env.gen_next_host(), ref.gen_next)
+        assert int(ref.overflow[0]) == 0 and int(ref.state["episode"].max()) >= 1
+    finally:
+        set_knobs(stream_legacy=0)
+
+
+class EmuKnobEnv(object):
+    def __init__(self, emu, size, E, base, spec):
+        self.env = emu.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E + 3, stream=spec)
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, a):
+        return self.env.step(a)
+
+    def ring(self):
+        return self.env.pool
+
+    def gen_next_host(self):
+        return self.env.gen_next
+
+
+@pytest.mark.parametrize("size,E,depth,steps,pattern", [
+    ((10, 10, 10), 130, 8, 40, "fast"), ((10, 10, 10), 130, 8, 40, "alternate"), ((10, 10, 10), 67, 5, 30, "thirds"),
+    ((20, 20, 20), 9, 5, 12, "fast"),            # ~1100 outputs per sequence: every job twists its generator
+    ((20, 20, 20), 9, 5, 12, "alternate"),
+    ((8, 12, 9), 40, 6, 30, "fast"),
+    ((30, 30, 18), 2, 4, 2, "fast"),             # pending lists beyond the LDS part (peak ~120 entries, 80 in LDS)
+])
+def test_emulated_fast_and_plain_refill_interchangeable(emu, oracle, size, E, depth, steps, pattern):
+    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2}[pattern]
+    knob_check(lambda sz, n, base, spec: EmuKnobEnv(emu, sz, n, base, spec), oracle,
+               lambda **kw: emu.set_knobs(**kw), size, E, depth, steps, pat)
+
+
+def test_emulated_refill_after_many_episodes_without_refill(emu, oracle):
+    """A caller that refills too rarely loses rows (contract: refill_every <= depth - 3) but never the stream position:
+    generators advance by every sequence, the last `depth` ones are in the ring."""
+    size, E, D, base = (10, 10, 10), 70, 4, 5
+    spec = dict(bound=(2, 5), seed=11, depth=D, refill_every=1)
+    env = emu.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E, stream=spec)
+    ref = oracle.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E, stream=spec)
+    for o in (env, ref):
+        o.reset()
+        o.refill_every = 10 ** 9                     # from here on only the explicit refill below
+        o.state["episode"][: E // 2] += np.arange(E // 2, dtype=np.int32) % 9   # up to 8 episodes behind, more than depth
+        o.refill()
+    np.testing.assert_array_equal(env.pool, ref.pool)
+    np.testing.assert_array_equal(env.gen_next, ref.gen_next)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,rot,E,steps,depth,refill,native", [((10, 10, 10), False, 4099, 120, 8, 5, False),
                                                                   ((10, 10, 10), True, 2000, 300, 8, 5, True),
@@ -147,3 +220,75 @@ def test_gpu_stream_env_checkpoint_resume_and_factory():
     envs = bpp_amd.make_vec_envs("Bpp-v0", 1, 16, 1.0, None, "cuda:0", False, args=args, stream=spec)
     obs = envs.reset()
     assert tuple(obs.shape) == (16, 400) and envs._stream is not None
+
+
+class GpuKnobEnv(object):
+    def __init__(self, size, E, base, spec):
+        import bpp_amd
+        self.env = bpp_amd.BppVecEnv(E, size, enable_rotation=False, stream=spec, env_id_base=base, env_id_total=base + E + 3)
+
+    def reset(self):
+        obs = self.env.reset()
+        return obs.cpu().numpy(), self.env.location_masks.cpu().numpy()
+
+    def step(self, a):
+        r = self.env.step_tensors(np.asarray(a))
+        out = {k: getattr(r, k).cpu().numpy() for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len")}
+        out["reward"] = r.reward.cpu().numpy()[:, 0]
+        return out
+
+    def ring(self):
+        return self.env.pool.cpu().numpy()
+
+    def gen_next_host(self):
+        return self.env.gen_next.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,E,depth,steps,pattern", [
+    ((10, 10, 10), 5000, 8, 60, "fast"), ((10, 10, 10), 5000, 8, 60, "alternate"), ((10, 10, 10), 777, 5, 40, "thirds"),
+    ((20, 20, 20), 200, 5, 40, "fast"), ((20, 20, 20), 130, 5, 20, "alternate"), ((8, 12, 9), 300, 6, 40, "fast"),
+    ((30, 30, 18), 70, 4, 3, "fast"),
+])
+def test_gpu_fast_and_plain_refill_interchangeable(oracle, size, E, depth, steps, pattern):
+    import bpp_amd
+    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2}[pattern]
+    knob_check(GpuKnobEnv, oracle, lambda **kw: bpp_amd._lib.set_knobs(**kw), size, E, depth, steps, pat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,E,depth,refill,steps", [((10, 10, 10), 65536, 16, 6, 64), ((10, 10, 10), 3001, 9, 3, 100),
+                                                       ((20, 20, 20), 1024, 12, 4, 80)])
+def test_gpu_refill_beside_the_lock_steps_changes_nothing(oracle, size, E, depth, refill, steps):
+    """bpp_rollout_uniform_stream with depth >= 2 * refill_every + 3: refills run on the library's side stream while the
+    next lock-steps execute.  Outputs, state records, generator progress and ring equal the serial schedule's and the
+    oracle's; a knob turns the side stream off."""
+    import torch
+    import bpp_amd
+    spec = dict(bound=(2, 5), seed=21, depth=depth, refill_every=refill)
+    results = []
+    for overlap in (1, 0):
+        old = bpp_amd._lib.set_knobs(stream_overlap=overlap)
+        try:
+            env = bpp_amd.BppVecEnv(E, size, enable_rotation=False, stream=spec, env_id_base=17, env_id_total=17 + E)
+            env.reset()
+            acts = torch.empty(E, dtype=torch.int64, device=env.device)
+            r = env.rollout_uniform(4, 0, steps, actions=acts)
+            env.refill()
+            torch.cuda.synchronize()
+            results.append(dict(obs=r.obs.cpu().numpy(), mask=r.mask.cpu().numpy(), ep_ret=r.ep_ret.cpu().numpy(),
+                                acts=acts.cpu().numpy(), state=env.state.cpu().numpy(), ring=env.pool.cpu().numpy(),
+                                gen_next=env.gen_next.cpu().numpy()))
+            assert int(env.stream_overflow.item()) == 0
+        finally:
+            bpp_amd._lib.set_knobs(**old)
+    for k, v in results[0].items():
+        np.testing.assert_array_equal(v, results[1][k], err_msg=k)
+    ref = oracle.OracleEnv(None, size, False, E, env_id_base=17, env_id_total=17 + E, stream=spec)
+    ref.reset()
+    o, oa = oracle.rollout_uniform(ref, 4, 0, steps)
+    ref.refill()
+    np.testing.assert_array_equal(results[0]["acts"], oa)
+    np.testing.assert_array_equal(results[0]["obs"], o["obs"])
+    np.testing.assert_array_equal(results[0]["ring"], ref.pool)
+    np.testing.assert_array_equal(results[0]["gen_next"], ref.gen_next)

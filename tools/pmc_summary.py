@@ -15,6 +15,8 @@ for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
             k = "step"      # MODE == kStep is the last template argument
         elif "bpp_tile_kernel<" in k and k.split("bpp_tile_kernel<")[1].split(">(")[0].split(",")[4].strip() == "0":
             k = "step"      # bpp_tile_kernel<W, L, K, ROT, MODE, EPW, NIT>
+        elif "stream_" in k and "_kernel" in k:
+            k = k.split("stream_")[1].split("_kernel")[0]      # scan / cut / sort / refill / init
         else:
             k = "sample" if "sample_kernel" in k else ("stats" if "stats_kernel" in k else None)
         if k is None:
