@@ -2301,7 +2301,7 @@ StreamPlan plan_stream(const bpp_stream *s) {
     p.off_spill = (p.off_rows + (size_t)s->depth * E * 8 + 15) & ~(size_t)15;
     p.fast_bytes = p.off_spill + (size_t)2 * p.nsp * p.nslots * 4;
     p.legacy_bytes = (size_t)stream_work_entries(s->W, s->L, s->H, s->bound_lo) * E * 8;
-    p.cut_lds = ((size_t)(2 * p.cap + kRngWin) * 64 + kTwistWords) * 4;
+    p.cut_lds = (size_t)stream_cut_lds_words(p.cap) * 4;
     p.sort_lds = (size_t)4 * (s->pool_len + 256) * 4;
     p.fast = s->pool_len - 1 >= p.maxn && s->pool_len <= kSortMaxT && p.cut_lds <= 64 * 1024 && p.sort_lds <= 64 * 1024;
     return p;
@@ -2328,7 +2328,11 @@ int bpp_stream_init(const bpp_stream *s, void *stream) {
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
 
-int bpp_stream_refill(const bpp_stream *s, void *stream) {
+}  // extern "C"
+
+namespace {
+// kmax / urgent: see StreamWork.  The plain kernel always brings every bin to `depth` rows.
+int stream_refill(const bpp_stream *s, void *stream, int kmax, int urgent) {
     int rc = check_stream(s);
     if (rc) return rc;
     const StreamPlan p = plan_stream(s);
@@ -2341,17 +2345,25 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) {
     }
     unsigned char *base = (unsigned char *)s->work;
     const StreamWork w{(int32_t *)base, (int32_t *)(base + p.off_jobs), (int32_t *)(base + p.off_target), (int64_t *)(base + p.off_rows),
-                       (uint32_t *)(base + p.off_spill), p.cap, p.nsp, p.nslots, p.maxn};
+                       (uint32_t *)(base + p.off_spill), p.cap, p.nsp, p.nslots, p.maxn, kmax, urgent};
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     const int E = s->num_envs;
-    hipLaunchKernelGGL(stream_scan_kernel, dim3((E + 255) / 256), dim3(256), 0, st, *s, w);
+    hipLaunchKernelGGL(stream_scan_kernel, dim3((E + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 2 * (kScanThreads / 64) * 4 * sizeof(int), st,
+                       *s, w);
+    hipLaunchKernelGGL(stream_pretwist_kernel, dim3((unsigned)((E + 3) / 4 < 2048 ? (E + 3) / 4 : 2048)), dim3(256),
+                       4 * kTwistWords * sizeof(uint32_t), st, *s, w);
     hipLaunchKernelGGL(stream_cut_kernel, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
     const int64_t most = ((int64_t)E * s->depth + 3) / 4;
     hipLaunchKernelGGL(stream_sort_kernel, dim3((unsigned)(most < 2048 ? most : 2048)), dim3(256), p.sort_lds, st, *s, w);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
+}  // namespace
+
+extern "C" {
+
+int bpp_stream_refill(const bpp_stream *s, void *stream) { return stream_refill(s, stream, 0, 0); }
 
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
                                int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
@@ -2376,7 +2388,10 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
         }
         (void)hipEventRecord(side->stepped, main);
         (void)hipStreamWaitEvent(side->stream, side->stepped, 0);
-        rc = bpp_stream_refill(s, side->stream);
+        // beside the lock-steps a short refill matters more than a full ring: two sequences per bin and refill (the
+        // average bin uses refill_every / 9), more only for a bin that would otherwise run out before the refill after
+        // the next one is complete
+        rc = stream_refill(s, side->stream, 2, 2 * refill_every + 3);
         (void)hipEventRecord(side->refilled[chunk & 1], side->stream);
     }
     if (side) {     // everything enqueued on `stream` after this call sees the refilled ring
@@ -2384,6 +2399,7 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
         if (chunk >= 1) (void)hipStreamWaitEvent(main, side->refilled[(chunk - 1) & 1], 0);
         hipError_t e = hipGetLastError();
         if (rc == 0 && e != hipSuccess) rc = hip_fail(e, "side-stream refill");
+        if (rc == 0) rc = bpp_stream_refill(s, stream);     // leave every bin with `depth` rows, as the serial schedule does
     }
     return rc;
 }

@@ -34,7 +34,12 @@ class EmuStreamEnv(object):
 @pytest.mark.parametrize("size,rot,E,steps,depth,refill,native", [((10, 10, 10), False, 70, 60, 8, 5, False),
                                                                   ((10, 10, 10), True, 33, 40, 4, 1, False),
                                                                   ((10, 10, 10), False, 50, 80, 6, 3, True),
-                                                                  ((20, 20, 20), False, 5, 30, 5, 2, True)])
+                                                                  ((20, 20, 20), False, 5, 30, 5, 2, True),
+                                                                  # depth >= 2 * refill + 3: the driver's side-stream schedule
+                                                                  # (at most two sequences per bin and refill unless urgent)
+                                                                  ((10, 10, 10), False, 70, 50, 9, 3, True),
+                                                                  ((10, 10, 10), True, 40, 64, 20, 8, True),
+                                                                  ((20, 20, 20), False, 5, 30, 9, 3, True)])
 def test_emulated_stream_supply_matches_oracle_and_python_random(emu, oracle, size, rot, E, steps, depth, refill, native):
     spec_check(lambda sz, r, n, base, spec: EmuStreamEnv(emu, sz, r, n, base, spec), oracle, size, rot, E, steps, depth, refill, native)
 
