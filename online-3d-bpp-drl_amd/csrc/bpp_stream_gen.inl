@@ -182,14 +182,19 @@ struct ArrayVals {
 };
 
 // ---- per-bin generator record in bpp_stream.mt (opaque to callers; bpp_stream_sizes gives the size): kMtRec words per
-// bin, contiguous.  Two halves of 624 state words: the CURRENT MT19937 state and, when kMtNextOk is set, the state that
-// follows it (already twisted -- the fast pipeline regenerates states in a separate, fully parallel kernel so that a
-// generator running off the end of its state just changes halves).  Then the index of the next unused word of the
-// current state (0..624), which half is current, the flag, and up to 32 tempered outputs carried over from the last
-// refill (the cut kernel hands out outputs from a 32-word window and keeps what it did not use).
+// bin, contiguous:
+//   [0, 32)        header: [0] index of the next unused output of the CURRENT state (0..624), [1] which half is current,
+//                  [2] set when the other half already holds the state that FOLLOWS the current one;
+//   [32, 1280)     two halves of 624 raw MT19937 state words;
+//   [1280, 2528)   the same two halves tempered (= the outputs, in order);
+//   [2528, 2784)   copy of the first 256 tempered words of half 0, so that a run of outputs that starts in half 1 and
+//                  continues in its successor (half 0) is contiguous in memory like one that starts in half 0.
+// The fast pipeline regenerates states in a separate, fully parallel kernel (pretwist), so a generator that runs off the
+// end of its state just changes halves, and consuming outputs is reading memory: nothing is buffered between refills.
 constexpr int kMtHalf = 624;
-constexpr int kMtIdx = 2 * kMtHalf, kMtPar = kMtIdx + 1, kMtNextOk = kMtIdx + 2, kMtLeftN = kMtIdx + 3, kMtLeft = kMtIdx + 4;
-constexpr int kMtRec = 1312;            // 2 * 624 + 4 + 32 = 1284, padded to whole 128-byte lines
+constexpr int kMtPos = 0, kMtPar = 1, kMtNextOk = 2;
+constexpr int kMtRaw = 32, kMtOut = kMtRaw + 2 * kMtHalf, kMtMirror = kMtOut + 2 * kMtHalf, kMtMirrorLen = 256;
+constexpr int kMtRec = kMtMirror + kMtMirrorLen;     // 2784 words = 87 lines of 128 bytes
 
 __host__ __device__ inline int stream_work_entries(int W, int L, int H, int lo) { return W * L * H / (lo * lo * lo) + 8; }
 
@@ -205,16 +210,20 @@ __host__ __device__ inline uint32_t mt_temper(uint32_t y) {
 // Refill, fast pipeline: four kernels per bpp_stream_refill.
 //   scan     one lane per bin: which bins have used up rows since the last refill (jobs, bucketed by the number of
 //            sequences they need so that a wave's lanes finish together) and which ring rows will be rewritten;
-//   pretwist one wave per job whose generator has no successor state yet: the next 624 state words, coalesced, through LDS;
-//   cut      one lane per job, single-wave workgroups.  The list walk of mdCreator.py:117-135 is run as a state
-//            machine that consumes EXACTLY ONE 32-bit generator output per iteration (a rejected randbelow draw, a
-//            failed split attempt and a split are all one iteration), so the lanes of a wave stay converged, read
-//            their outputs from the same slot of a 32-word LDS window and refill that window together (the raw words of
-//            the next window are loaded one window ahead).  The pending boxes live in two LDS lists per lane (this
-//            pass / survivors for the next pass: no shifting, no compaction).  The iteration is written without
-//            divergent branches -- a wave alone on its SIMD pays ~13 cycles per instruction in branchy code, and every
-//            path is taken by some lane in every iteration anyway: stores that do not apply go to a dummy slot.  Cut
-//            boxes go straight into the ring row, unsorted, with their base height as sort key;
+//   pretwist one wave per job whose generator has no successor state yet: the next 624 state words and outputs,
+//            coalesced, through LDS;
+//   cut      one lane per job, single-wave workgroups.  The list walk of mdCreator.py:117-135 runs one VISIT (split
+//            attempt) per iteration: the two rejection loops of a visit -- random.choice over the long sides and
+//            random.randint for the cut position, each `getrandbits until below n` -- are evaluated on eight outputs at
+//            once (first accepted one wins, outputs before it are consumed), so that a visit is a short dependency chain
+//            instead of 3.4 dependent iterations; a lane that finds no accepted output among its eight carries on in
+//            the next iteration.  A wave alone on its SIMD is bound by dependent-instruction latency (~10 cycles per
+//            instruction in branchy code), hence: no divergent branches -- everything is computed, selects pick what
+//            applies, stores that do not apply go to a dummy word -- and work that can be done side by side.  Outputs
+//            come from a 64-word LDS ring per lane, topped up every eight iterations from words loaded eight iterations
+//            earlier.  The pending boxes live in two LDS lists per lane (this pass / survivors for the next pass: no
+//            shifting, no compaction).  Cut boxes go straight into the ring row, unsorted, with their base height as
+//            sort key;
 //   sort     one wave per rewritten row: stable counting sort by base height (depart_box, :137-138), key stripped,
 //            terminator padding.
 // Same draws in the same order as cut2_generate above (tests/test_stream_supply.py runs both against the oracle's
@@ -231,21 +240,24 @@ struct StreamWork {        // views into bpp_stream.work (see plan_stream)
     int32_t kmax, urgent;  // kmax > 0: a bin gets at most kmax sequences per refill unless that leaves it fewer than
                            // `urgent` rows from its current episode (then as many as it takes); 0: always all depth rows
 };
-constexpr int kRngWin = 32;            // generator outputs per window
+constexpr int kOutRing = 64;           // outputs a lane holds in LDS (+ kCand - 1 slots repeating the first ones, so that
+                                       // kCand consecutive outputs are consecutive slots wherever they start)
+constexpr int kOutFetch = 48;          // outputs loaded per top-up
+constexpr int kTopUpEvery = 8;         // iterations between top-ups
+constexpr int kCand = 8;               // outputs a rejection loop looks at per iteration
 constexpr int kTwistWords = 640;       // LDS scratch of a wave-wide twist (624 used)
 constexpr int kSortMaxT = 2048;        // longest row the sort kernel stages in LDS
 constexpr int kScanThreads = 1024;
 
 // LDS entries per pending list for sequences of at most maxn boxes.  Measured peaks: 10^3 bins 10 on average, above 16
 // in 0.5 % of the sequences, 21 at most in 3000; 20^3 bins 68.  Longer lists continue in global memory (the wave then
-// runs its general iteration).  10^3: 24 entries -> 23.3 KB per workgroup, which fits beside seven step-kernel
-// workgroups on a CU.
+// runs its general iteration).
 __host__ inline int stream_pend_cap(int maxn) {
     int c = (maxn / 18 + 16 + 7) / 8 * 8;
     c = c < 16 ? 16 : (c > 80 ? 80 : c);
     return c < maxn ? c : maxn;
 }
-__host__ __device__ inline int stream_cut_lds_words(int cap) { return (2 * cap + 1 + kRngWin) * 64 + kTwistWords; }
+__host__ __device__ inline int stream_cut_lds_words(int cap) { return (2 * cap + 1 + kOutRing + kCand) * 64 + kTwistWords; }
 
 __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(bpp_stream s, StreamWork w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * [waves][4] counters
@@ -289,11 +301,12 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(bpp_stream s,
     for (int k = 0; k < nr; ++k) w.rows[at + k] = (int64_t)(uint32_t)e | ((int64_t)(first + k) << 32);
 }
 
-// The whole wave computes the 624 state words that follow `src` into `dst` (both global, may be the same; tw: LDS
-// scratch).  Word k needs the OLD words k and k+1 and word k+397 (old for k < 227, else the NEW word k-227); walking k in
-// rounds of 64 consecutive words with all reads of a round before its writes gives every lane exactly those values
-// (word 623 reads the new word 0, as the serial loop does).
-__device__ __forceinline__ void stream_wave_twist(const uint32_t *src, uint32_t *dst, uint32_t *tw, int lane) {
+// The whole wave computes the state that follows half `par` of a record into the other half: raw words, outputs and,
+// for half 0, the mirror (tw: LDS scratch).  Word k needs the OLD words k and k+1 and word k+397 (old for k < 227, else
+// the NEW word k-227); walking k in rounds of 64 consecutive words with all reads of a round before its writes gives
+// every lane exactly those values (word 623 reads the new word 0, as the serial loop does).
+__device__ __forceinline__ void stream_wave_twist(uint32_t *rec, uint32_t par, uint32_t *tw, int lane) {
+    const uint32_t *src = rec + kMtRaw + par * kMtHalf;
     for (int k = lane; k < 624; k += 64) tw[k] = src[k];
     wave_sync();
     for (int k0 = 0; k0 < 624; k0 += 64) {
@@ -311,7 +324,13 @@ __device__ __forceinline__ void stream_wave_twist(const uint32_t *src, uint32_t 
         }
         wave_sync();
     }
-    for (int k = lane; k < 624; k += 64) dst[k] = tw[k];
+    const uint32_t to = par ^ 1u;
+    for (int k = lane; k < 624; k += 64) {
+        const uint32_t y = tw[k], t = mt_temper(y);
+        rec[kMtRaw + to * kMtHalf + k] = y;
+        rec[kMtOut + to * kMtHalf + k] = t;
+        if (to == 0u && k < kMtMirrorLen) rec[kMtMirror + k] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void stream_pretwist_kernel(bpp_stream s, StreamWork w) {
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(256) void stream_pretwist_kernel(bpp_stream s, Stre
         if (rec[kMtNextOk] == 0u) {
             const uint32_t par = rec[kMtPar];
             wave_sync();
-            stream_wave_twist(rec + par * kMtHalf, rec + (par ^ 1u) * kMtHalf, scratch[wave], lane);
+            stream_wave_twist(rec, par, scratch[wave], lane);
             if (lane == 0) rec[kMtNextOk] = 1u;
         }
         wave_sync();
@@ -357,86 +376,168 @@ struct CutLane {
     int side;               // which LDS list is this pass's (0 / 1)
     int nv;                 // boxes cut so far
     uint32_t *row;
+    int used;               // outputs consumed since the job started
 };
 
-// One output, general form: any list length (entries beyond the LDS part live in global memory).  Returns true when the
-// sequence is complete.  mdCreator.py line numbers as in cut2_generate.
-__device__ __forceinline__ bool cut_step_general(CutLane &c, const PendLists &pend, uint32_t u, uint32_t lo, uint32_t hi) {
-    const uint32_t bx = c.box & 255u, by = (c.box >> 8) & 255u, bz = (c.box >> 16) & 255u;
-    const bool fx = bx > hi, fy = by > hi, fz = bz > hi;            // :60-66
-    const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
-    int outcome = 0;                                                  // 1: the attempt failed, 2: split
-    uint32_t r = 0;
-    if (c.st == 0) {                                                  // random.choice(flags), :68
-        const uint32_t x = u >> (nf == 1u ? 31 : 30);                // getrandbits(bit_length(nf))
-        if (x < nf) {
-            c.f = x == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x == 1u ? ((fx && fy) ? 1 : 2) : 2);
-            c.v = c.f == 0 ? bx : (c.f == 1 ? by : bz);
-            if (c.f == 0 ? c.v <= lo : c.v < lo) outcome = 1;         // :71, :81, :91
-            else c.st = 1;
-        }
-    } else {                                                          // random.randint(1, v), :73 / :83 / :93
-        const uint32_t x = u >> __clz((int)c.v);                      // getrandbits(bit_length(v))
-        if (x < c.v) {
-            r = x + 1u;
-            outcome = (r < lo || c.v - r < lo) ? 1 : 2;               // :74, :84, :94
-        }
+// `getrandbits(k) until below lim` on the (at most kCand) outputs the lane holds from position `from` of its ring:
+// index of the first accepted output and its value; kCand when none is accepted.  The compares are independent of each
+// other -- this is where a visit's serial chain of draws becomes work done side by side.
+__device__ __forceinline__ void first_below(const uint32_t *ring, int from, uint32_t shift, uint32_t lim, int &first, uint32_t &x) {
+    uint32_t u[kCand];
+#pragma unroll
+    for (int j = 0; j < kCand; ++j) u[j] = ring[((from + j) & (kOutRing - 1)) * 64];
+    first = kCand;
+    x = 0;
+#pragma unroll
+    for (int j = kCand - 1; j >= 0; --j) {
+        const uint32_t xj = u[j] >> shift;
+        const bool a = xj < lim;
+        first = a ? j : first;
+        x = a ? xj : x;
     }
-    if (outcome == 1) {
-        pend.set(c.side ^ 1, c.tail_b++, c.box);                      // stays in invalid_box for the next pass
-    } else if (outcome == 2) {
-        const uint32_t sh = 8u * (uint32_t)c.f, p1 = c.f == 2 ? c.v - r : r, p2 = c.v - p1;
-        const uint32_t rest = c.box & ~(255u << sh);
-        const uint32_t c1 = rest | (p1 << sh);
-        const uint32_t c2 = (rest | (p2 << sh)) + (c.f == 2 ? p1 << 24 : 0u);   // :97-98: the upper part starts at high - r
-        // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
-        if (nf == 1u && p1 <= hi) c.row[c.nv++] = c1;
-        else pend.set(c.side, c.tail_a++, c1);                        // appended: visited later in this pass
-        if (nf == 1u && p2 <= hi) c.row[c.nv++] = c2;
-        else pend.set(c.side, c.tail_a++, c2);
-    }
-    if (!outcome) return false;
-    ++c.i;
-    if (outcome == 2 && c.i < c.tail_a) {     // the removal slid the next box under the iterator: not visited in this pass
-        pend.set(c.side ^ 1, c.tail_b++, pend.get(c.side, c.i));
-        ++c.i;
-    }
-    bool finished = false;
-    if (c.i >= c.tail_a) {                    // end of the `for`: next pass over the survivors, or done
-        finished = c.tail_b == 0;
-        c.side ^= 1;
-        c.tail_a = c.tail_b;
-        c.tail_b = 0;
-        c.i = 0;
-    }
-    c.st = 0;
-    if (!finished) c.box = pend.get(c.side, c.i);
-    return finished;
 }
 
-// The same step for lanes whose lists are certain to stay inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap), written
-// without divergent branches: everything is computed, selects pick what applies, and a store that does not apply goes
-// to the lane's dummy word.  (`f == 0 ? v <= lo : v < lo`, :71 / :81 / :91, cannot hold: the side was chosen because it
-// exceeds hi, and bpp_stream requires hi >= 2 lo - 1 >= lo.)
-__device__ __forceinline__ bool cut_step_lds(CutLane &c, uint32_t *col, int cap, bool active, uint32_t u, uint32_t lo, uint32_t hi) {
-    const int dummy = 2 * cap;
+// ---- predicates as all-ones / zero words.  On this part a v_cndmask_b32 costs as much as five to nine plain vector
+// instructions (tools/ubench.hip: 9.8 ns per wave against 1.1 - 1.8 ns), so the branch-free visit below selects with
+// and / or / bit-field-insert on such masks instead.  All operands are small non-negative numbers (< 2^31).
+__device__ __forceinline__ uint32_t m_lt(uint32_t a, uint32_t b) { return (uint32_t)((int32_t)(a - b) >> 31); }   // a < b
+__device__ __forceinline__ uint32_t m_eq(uint32_t a, uint32_t b) { return m_lt(a ^ b, 1u); }
+__device__ __forceinline__ uint32_t m_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }       // m ? a : b
+
+// `getrandbits(k) until below lim` on the kCand outputs that follow position `from` of the lane's ring: the first accepted
+// output wins.  Every output becomes a key -- position << 8 | value when accepted, above 0xffff when not -- and the
+// smallest key is the answer; the keys are independent of each other, which is what turns a visit's serial chain of
+// draws into work done side by side.  Returns the key: position = key >> 8 (>= 256: none accepted), value = key & 255.
+__device__ __forceinline__ uint32_t first_below_key(const uint32_t *ring, int from, uint32_t shift, uint32_t lim) {
+    const uint32_t *p = ring + (from & (kOutRing - 1)) * 64;
+    const uint32_t lim1 = lim - 1u;
+    uint32_t k[kCand];
+#pragma unroll
+    for (int j = 0; j < kCand; ++j) {
+        const uint32_t xj = p[j * 64] >> shift;
+        k[j] = (((lim1 - xj) >> 31) << 16) | (xj | ((uint32_t)j << 8));
+    }
+    static_assert(kCand == 8, "min tree below is written for eight candidates");
+    return min(min(min(k[0], k[1]), min(k[2], k[3])), min(min(k[4], k[5]), min(k[6], k[7])));
+}
+
+// One visit for a lane whose lists are certain to stay inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap): the statement
+// of cut_visit<true> below without divergent branches and without selects on condition codes.  `act` is the lane's
+// all-ones / zero activity mask; returns the mask "sequence complete".
+__device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int cap, const uint32_t *ring, int filled, uint32_t act,
+                                                  uint32_t lo, uint32_t hi) {
+    const uint32_t dummy = 2u * (uint32_t)cap;
+    const uint32_t abase = (uint32_t)cap & (0u - (uint32_t)c.side), bbase = (uint32_t)cap - abase;
+    const uint32_t box = c.box;
+    const uint32_t bx = box & 255u, by = (box >> 8) & 255u, bz = (box >> 16) & 255u;
+    const uint32_t mfx = m_lt(hi, bx), mfy = m_lt(hi, by), mfz = m_lt(hi, bz);          // :60-66
+    const uint32_t nf = 0u - (mfx + mfy + mfz);
+    const uint32_t monly = m_eq(nf, 1u);
+    const uint32_t mst0 = (uint32_t)c.st - 1u;                                          // st is 0 or 1
+    // random.choice(flags) (:68), or random.randint(1, v) (:73 / :83 / :93) for a lane that chose its side earlier
+    const uint32_t key1 = first_below_key(ring, c.used, m_sel(mst0, 30u - monly, (uint32_t)__clz((int)c.v)), m_sel(mst0, nf, c.v));
+    const uint32_t have1 = (uint32_t)min(filled - c.used, kCand);
+    const uint32_t first1 = key1 >> 8, x1 = key1 & 255u;
+    const uint32_t mfound1 = m_lt(first1, have1) & act;
+    c.used += (int)(m_sel(mfound1, first1 + 1u, have1) & act);
+    const uint32_t mchoose = mfound1 & mst0;
+    const uint32_t f0 = (2u + mfy) & ~mfx;                                              // first long side
+    const uint32_t f1 = 2u + (mfx & mfy);                                               // second long side
+    const uint32_t fnew = m_sel(m_lt(x1, 1u), f0, m_sel(m_eq(x1, 1u), f1, 2u));
+    const uint32_t f = m_sel(mchoose, fnew, (uint32_t)c.f);
+    const uint32_t v = m_sel(mchoose, (box >> (8u * fnew)) & 255u, c.v);
+    // the cut position for a side chosen just now
+    const uint32_t key2 = first_below_key(ring, c.used, (uint32_t)__clz((int)v), v);
+    const uint32_t have2 = (uint32_t)min(filled - c.used, kCand);
+    const uint32_t first2 = key2 >> 8, x2 = key2 & 255u;
+    const uint32_t mfound2 = m_lt(first2, have2) & mchoose;
+    c.used += (int)(m_sel(mfound2, first2 + 1u, have2) & mchoose);
+    const uint32_t mfin = (mfound1 & ~mst0) | mfound2;                                  // the visit is decided
+    const uint32_t r = m_sel(mfound2, x2, x1) + 1u;
+    const uint32_t mgood = ~(m_lt(r, lo) | m_lt(v - r, lo));                            // :74, :84, :94
+    const uint32_t msplit = mfin & mgood, mfail = mfin & ~mgood;
+    const uint32_t mf2 = m_eq(f, 2u);
+    const uint32_t sh = 8u * f, p1 = m_sel(mf2, v - r, r), p2 = v - p1;
+    const uint32_t rest = box & ~(255u << sh);
+    const uint32_t c1 = rest | (p1 << sh);
+    const uint32_t c2 = (rest | (p2 << sh)) + ((p1 << 24) & mf2);                       // :97-98: the upper part starts at high - r
+    const uint32_t me1 = msplit & monly & ~m_lt(hi, p1), me2 = msplit & monly & ~m_lt(hi, p2);   // is_valid, :110-115
+    const uint32_t mq1 = msplit & ~me1, mq2 = msplit & ~me2;
+    uint32_t nv = (uint32_t)c.nv, tail_a = (uint32_t)c.tail_a, tail_b = (uint32_t)c.tail_b, i = (uint32_t)c.i;
+    if (me1) c.row[nv] = c1;
+    nv -= me1;
+    if (me2) c.row[nv] = c2;
+    nv -= me2;
+    col[m_sel(mfail, bbase + tail_b, dummy) * 64] = box;          // stays in invalid_box for the next pass
+    tail_b -= mfail;
+    col[m_sel(mq1, abase + tail_a, dummy) * 64] = c1;             // appended: visited later in this pass
+    tail_a -= mq1;
+    col[m_sel(mq2, abase + tail_a, dummy) * 64] = c2;
+    tail_a -= mq2;
+    c.st = (int)(((uint32_t)c.st | (mchoose & 1u)) & ~mfin);
+    c.f = (int)f;
+    c.v = v;
+    i -= mfin;
+    // the two entries after the visited box (the first is skipped after a split, :124) and the head of the survivors
+    const uint32_t n1 = col[(abase + min(i, (uint32_t)cap - 1u)) * 64], n2 = col[(abase + min(i + 1u, (uint32_t)cap - 1u)) * 64];
+    const uint32_t mskip = msplit & m_lt(i, tail_a);
+    col[m_sel(mskip, bbase + tail_b, dummy) * 64] = n1;
+    tail_b -= mskip;
+    i -= mskip;
+    const uint32_t b0 = col[bbase * 64];
+    const uint32_t mpass = mfin & ~m_lt(i, tail_a);               // end of the `for`: next pass over the survivors, or done
+    const uint32_t mdone = mpass & m_eq(tail_b, 0u);
+    c.box = m_sel(mfin, m_sel(mpass, b0, m_sel(mskip, n2, n1)), box);
+    c.side ^= (int)(mpass & 1u);
+    c.tail_a = (int)m_sel(mpass, tail_b, tail_a);
+    c.tail_b = (int)(tail_b & ~mpass);
+    c.i = (int)(i & ~mpass);
+    c.nv = (int)nv;
+    return mdone;
+}
+
+// One visit (mdCreator.py:59-100 benchmark_split and its bookkeeping in gen_benchmark :120-130), or the part of it the
+// lane has outputs for.  `have` = outputs in the ring from c.used on.  SPILL = false: the lists are certain to stay
+// inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap) and the code has no divergent branch: a store that does not apply
+// goes to the lane's dummy word.  SPILL = true: any list length, entries beyond the LDS part in global memory.  Returns
+// true when the sequence is complete.  (`f == 0 ? v <= lo : v < lo`, :71 / :81 / :91, cannot hold: the side was chosen
+// because it exceeds hi, and bpp_stream requires hi >= 2 lo - 1 >= lo; cut2_generate keeps the test.)
+template <bool SPILL>
+__device__ __forceinline__ bool cut_visit(CutLane &c, const PendLists &pend, const uint32_t *ring, int filled, bool active,
+                                          uint32_t lo, uint32_t hi) {
+    uint32_t *col = pend.lds;
+    const int cap = pend.cap, dummy = 2 * cap;
     const int abase = c.side ? cap : 0, bbase = cap - abase;
     const uint32_t bx = c.box & 255u, by = (c.box >> 8) & 255u, bz = (c.box >> 16) & 255u;
-    const bool fx = bx > hi, fy = by > hi, fz = bz > hi;
+    const bool fx = bx > hi, fy = by > hi, fz = bz > hi;                    // :60-66
     const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
     const bool st0 = c.st == 0;
-    const uint32_t x = u >> (st0 ? (nf == 1u ? 31u : 30u) : (uint32_t)__clz((int)c.v));
-    const bool acc = active & (x < (st0 ? nf : c.v));
-    const int fnew = x == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x == 1u ? ((fx & fy) ? 1 : 2) : 2);
-    const uint32_t vnew = fnew == 0 ? bx : (fnew == 1 ? by : bz);
-    const bool choose = acc & st0, fin = acc & !st0;
-    const uint32_t r = x + 1u;
-    const bool good = (r >= lo) & (c.v - r >= lo);
+    // first rejection loop of the iteration: random.choice(flags) (:68) = flags[getrandbits(bit_length(nf)) until < nf],
+    // or, for a lane that chose its side earlier, random.randint(1, v) (:73 / :83 / :93) = 1 + (getrandbits(bit_length(v)) until < v)
+    int first1, first2;
+    uint32_t x1, x2;
+    first_below(ring, c.used, st0 ? (nf == 1u ? 31u : 30u) : (uint32_t)__clz((int)c.v), st0 ? nf : c.v, first1, x1);
+    const int have1 = min(filled - c.used, kCand);
+    const bool found1 = active & (first1 < have1);
+    c.used += active ? (found1 ? first1 + 1 : have1) : 0;
+    const bool choose = found1 & st0;
+    const int fnew = x1 == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x1 == 1u ? ((fx & fy) ? 1 : 2) : 2);
+    const int f = choose ? fnew : c.f;
+    const uint32_t v = choose ? (fnew == 0 ? bx : (fnew == 1 ? by : bz)) : c.v;
+    // second one: the cut position for a side chosen just now
+    first_below(ring, c.used, (uint32_t)__clz((int)v), v, first2, x2);
+    const int have2 = min(filled - c.used, kCand);
+    const bool found2 = choose & (first2 < have2);
+    c.used += choose ? (found2 ? first2 + 1 : have2) : 0;
+    const bool fin = (found1 & !st0) | found2;                                // the visit is decided
+    const uint32_t r = (found2 ? x2 : x1) + 1u;
+    const bool good = (r >= lo) & (v - r >= lo);                              // :74, :84, :94
     const bool split = fin & good, failv = fin & !good;
-    const uint32_t sh = 8u * (uint32_t)c.f, p1 = c.f == 2 ? c.v - r : r, p2 = c.v - p1;
+    const uint32_t sh = 8u * (uint32_t)f, p1 = f == 2 ? v - r : r, p2 = v - p1;
     const uint32_t rest = c.box & ~(255u << sh);
     const uint32_t c1 = rest | (p1 << sh);
-    const uint32_t c2 = (rest | (p2 << sh)) + (c.f == 2 ? p1 << 24 : 0u);
+    const uint32_t c2 = (rest | (p2 << sh)) + (f == 2 ? p1 << 24 : 0u);      // :97-98: the upper part starts at high - r
+    // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
     const bool only = nf == 1u;
     const bool e1 = split & only & (p1 <= hi), e2 = split & only & (p2 <= hi);
     const bool q1 = split & !e1, q2 = split & !e2;
@@ -444,28 +545,44 @@ __device__ __forceinline__ bool cut_step_lds(CutLane &c, uint32_t *col, int cap,
     c.nv += e1;
     if (e2) c.row[c.nv] = c2;
     c.nv += e2;
-    col[(failv ? bbase + c.tail_b : dummy) * 64] = c.box;
-    c.tail_b += failv;
-    col[(q1 ? abase + c.tail_a : dummy) * 64] = c1;
-    c.tail_a += q1;
-    col[(q2 ? abase + c.tail_a : dummy) * 64] = c2;
-    c.tail_a += q2;
-    c.st = choose ? 1 : (fin ? 0 : c.st);
-    c.f = choose ? fnew : c.f;
-    c.v = choose ? vnew : c.v;
-    c.i += fin;
-    // the two entries after the visited box (the first is skipped after a split, :124) and, written below, the head
-    // of the survivors
-    const uint32_t n1 = col[(abase + min(c.i, cap - 1)) * 64], n2 = col[(abase + min(c.i + 1, cap - 1)) * 64];
-    const bool skip = split & (c.i < c.tail_a);
-    col[(skip ? bbase + c.tail_b : dummy) * 64] = n1;
-    c.tail_b += skip;
-    c.i += skip;
-    const uint32_t b0 = col[bbase * 64];
-    const bool pass_end = fin & (c.i >= c.tail_a);
+    c.st = fin ? 0 : (choose ? 1 : c.st);
+    c.f = f;
+    c.v = v;
+    bool pass_end;
+    uint32_t next = 0;
+    if (SPILL) {
+        if (failv) pend.set(c.side ^ 1, c.tail_b++, c.box);                   // stays in invalid_box for the next pass
+        if (q1) pend.set(c.side, c.tail_a++, c1);                             // appended: visited later in this pass
+        if (q2) pend.set(c.side, c.tail_a++, c2);
+        c.i += fin;
+        if (split && c.i < c.tail_a) {            // the removal slid the next box under the iterator: not visited in this pass
+            pend.set(c.side ^ 1, c.tail_b++, pend.get(c.side, c.i));
+            ++c.i;
+        }
+        pass_end = fin && c.i >= c.tail_a;
+        if (fin && !pass_end) next = pend.get(c.side, c.i);
+        else if (pass_end && c.tail_b > 0) next = pend.get(c.side ^ 1, 0);
+    } else {
+        col[(failv ? bbase + c.tail_b : dummy) * 64] = c.box;
+        c.tail_b += failv;
+        col[(q1 ? abase + c.tail_a : dummy) * 64] = c1;
+        c.tail_a += q1;
+        col[(q2 ? abase + c.tail_a : dummy) * 64] = c2;
+        c.tail_a += q2;
+        c.i += fin;
+        // the two entries after the visited box (the first is skipped after a split, :124) and the head of the survivors
+        const uint32_t n1 = col[(abase + min(c.i, cap - 1)) * 64], n2 = col[(abase + min(c.i + 1, cap - 1)) * 64];
+        const bool skip = split & (c.i < c.tail_a);
+        col[(skip ? bbase + c.tail_b : dummy) * 64] = n1;
+        c.tail_b += skip;
+        c.i += skip;
+        const uint32_t b0 = col[bbase * 64];
+        pass_end = fin & (c.i >= c.tail_a);
+        next = pass_end ? b0 : (skip ? n2 : n1);
+    }
     const bool finished = pass_end & (c.tail_b == 0);
-    c.box = fin ? (pass_end ? b0 : (skip ? n2 : n1)) : c.box;
-    c.side = pass_end ? c.side ^ 1 : c.side;
+    c.box = fin ? next : c.box;
+    c.side = pass_end ? c.side ^ 1 : c.side;      // end of the `for`: next pass over the survivors, or done
     c.tail_a = pass_end ? c.tail_b : c.tail_a;
     c.tail_b = pass_end ? 0 : c.tail_b;
     c.i = pass_end ? 0 : c.i;
@@ -491,86 +608,74 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     const int e = job ? w.jobs[(size_t)bucket * E + j] : 0;
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
     uint32_t *col = lds + lane;                                     // word w of this lane at col[w * 64]
-    uint32_t *buf = col + (size_t)(2 * cap + 1) * 64;               // output window: slot q at buf[q * 64]
-    uint32_t *tw = lds + (size_t)(2 * cap + 1 + kRngWin) * 64;      // twist scratch of the wave
+    uint32_t *ring = col + (size_t)(2 * cap + 1) * 64;              // outputs: position p (counted from the job's start) at ring[(p % 64) * 64]
+    uint32_t *tw = lds + (size_t)(2 * cap + 1 + kOutRing + kCand) * 64;   // twist scratch of the wave
     const PendLists pend{col, w.spill + (size_t)blockIdx.x * 64 + lane, cap, w.nsp, (size_t)w.nslots};
 
-    int idx = 0, g = 0, need = 0, carried = 0;
+    int g = 0, need = 0, base = 0;                                   // base: index in the current state of the job's first output
     uint32_t par = 0, next_ok = 0;
     if (job) {
-        idx = (int)rec[kMtIdx];
+        base = (int)rec[kMtPos];
         par = rec[kMtPar];
         next_ok = rec[kMtNextOk];
-        carried = (int)rec[kMtLeftN];
         g = s.gen_next[e];
         need = w.target[e] - g;
-        for (int q = 0; q < kRngWin; ++q)
-            if (q < carried) buf[q * 64] = rec[kMtLeft + q];
     }
     bool active = job && need > 0;
     const bool ran = active;
-    const uint32_t *cur = rec + par * kMtHalf, *nxt = rec + (par ^ 1u) * kMtHalf;
+    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    CutLane c{whole, 1u, 0, 0, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T, 0};
+    if (active) col[0] = whole;
+    int filled = 0;                                                  // outputs put into the ring since the job started
 
-    // raw state words of the coming window, loaded one window ahead: slot q takes word idx + q - from (from > 0 only
-    // for the first window, whose first slots hold the carried outputs); past the end of the current state they come
-    // from its successor, which the pretwist kernel prepared -- or, for a job on its second lap, the wave makes it now
-    uint32_t raw[kRngWin];
-    auto fetch = [&](bool want, int from) {
-        uint64_t m = __ballot(want && idx + kRngWin - from > kMtHalf && !next_ok);
+    // The next kOutFetch outputs after `filled`, loaded one top-up ahead.  Outputs of the current state and of its
+    // successor are contiguous in the record (mirror); the successor is there (pretwist kernel) -- except for a job on
+    // its second lap, for which the wave makes it now.
+    uint32_t pre[kOutFetch];
+    auto fetch = [&]() {
+        uint64_t m = __ballot(active && base + filled + kOutFetch > kMtHalf && !next_ok);
         while (m) {                                   // wave-uniform, rare: one bin at a time, all lanes help
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const int el = (int)__builtin_amdgcn_readlane(e, l);
             const uint32_t pl = __builtin_amdgcn_readlane(par, l);
-            uint32_t *rl = s.mt + (size_t)el * kMtRec;
             wave_sync();
-            stream_wave_twist(rl + pl * kMtHalf, rl + (pl ^ 1u) * kMtHalf, tw, lane);
+            stream_wave_twist(s.mt + (size_t)el * kMtRec, pl, tw, lane);
             wave_sync();
             if (lane == l) next_ok = 1u;
         }
+        const uint32_t *p = rec + kMtOut + par * kMtHalf + base + filled;     // in-bounds for every lane, read or not
 #pragma unroll
-        for (int q = 0; q < kRngWin; ++q) {           // unconditional loads from addresses that always exist
-            const int k = max(idx + q - from, 0);
-            raw[q] = *(k < kMtHalf ? cur + k : nxt + (k - kMtHalf));
-        }
+        for (int q = 0; q < kOutFetch; ++q) pre[q] = p[q];
     };
-    uint32_t *const dummy = col + (size_t)(2 * cap) * 64;
-    auto install = [&](bool want, int from) {
+    auto top_up = [&]() {
+        const int room = kOutRing - (filled - c.used);
+        const int put = active ? min(kOutFetch, room) : 0;
 #pragma unroll
-        for (int q = 0; q < kRngWin; ++q) *((want && q >= from) ? buf + q * 64 : dummy) = mt_temper(raw[q]);
-        const int adv = want ? kRngWin - from : 0;
-        idx += adv;
-        if (idx > kMtHalf) {                          // now drawing from the successor
-            idx -= kMtHalf;
-            const uint32_t *t = cur;
-            cur = nxt;
-            nxt = t;
+        for (int q = 0; q < kOutFetch; ++q) {
+            const uint32_t slot = (uint32_t)(filled + q) & (kOutRing - 1), mput = m_lt((uint32_t)q, (uint32_t)put);
+            ring[m_sel(mput, slot, kOutRing + kCand - 1) * 64] = pre[q];                        // (else: the dummy word, below)
+            ring[m_sel(mput & m_lt(slot, kCand - 1), slot + kOutRing, kOutRing + kCand - 1) * 64] = pre[q];   // repeated first slots
+        }
+        filled += put;
+        if (active && base + c.used >= kMtHalf) {     // the lane now draws from the successor: it becomes the current state
+            base -= kMtHalf;
             par ^= 1u;
             next_ok = 0u;
         }
     };
-    fetch(active, carried);
-
-    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
-    CutLane c{whole, 0u, 0, 0, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T};
-    if (active) col[0] = whole;
-    int pos = kRngWin, endpos = 0, from = carried;
-    uint32_t un = 0;
+    fetch();
+    int it = 0;
     while (__ballot(active)) {
-        if (pos == kRngWin) {                         // wave-uniform: every 32 outputs
-            install(active, from);
-            from = 0;
-            fetch(active, 0);
-            pos = 0;
-            un = buf[0];
+        if ((it & (kTopUpEvery - 1)) == 0) {          // wave-uniform
+            top_up();
+            fetch();
         }
-        const uint32_t u = un;
-        un = buf[(pos + 1 < kRngWin ? pos + 1 : pos) * 64];          // the next iteration's output
         bool finished;
         if (__ballot(active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap))) {   // wave-uniform: a list may leave LDS
-            finished = active ? cut_step_general(c, pend, u, lo, hi) : false;
+            finished = active ? cut_visit<true>(c, pend, ring, filled, true, lo, hi) : false;
         } else {
-            finished = cut_step_lds(c, col, cap, active, u, lo, hi);
+            finished = cut_visit_lds(c, col, cap, ring, filled, active ? ~0u : 0u, lo, hi) != 0u;
         }
         if (finished) {
             c.row[T - 1] = (uint32_t)c.nv;            // length for the sort kernel (which restores the terminator)
@@ -583,18 +688,20 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
                 c.box = whole;
             } else {
                 active = false;
-                endpos = pos + 1;
             }
         }
-        ++pos;
+        ++it;
     }
-    if (ran) {                                        // keep the outputs of the window that were not used
-        rec[kMtIdx] = (uint32_t)idx;
+    if (ran) {                                        // outputs in the ring that were not used are simply read again next time
+        int pos = base + c.used;
+        if (pos >= kMtHalf) {
+            pos -= kMtHalf;
+            par ^= 1u;
+            next_ok = 0u;
+        }
+        rec[kMtPos] = (uint32_t)pos;
         rec[kMtPar] = par;
         rec[kMtNextOk] = next_ok;
-        rec[kMtLeftN] = (uint32_t)(kRngWin - endpos);
-        for (int q = 0; q < kRngWin; ++q)
-            if (q >= endpos) rec[kMtLeft + q - endpos] = buf[q * 64];
         s.gen_next[e] = g;
     }
 }
@@ -697,28 +804,25 @@ struct LdsVals {
     }
 };
 
-// CPython's random.Random for one bin: the bin's record in global memory, tempered outputs handed out from an LDS
-// buffer (first the outputs a fast refill left over, then fresh ones; a refill of the buffer never crosses a twist, so
-// unused outputs are returned by stepping the index back).
+// CPython's random.Random for one bin: the current state in the bin's record, tempered outputs handed out from an LDS
+// buffer (a refill of the buffer never crosses the end of the state, so unused outputs are returned by stepping the
+// index back).
 struct BufferedMT {
-    uint32_t *mt;       // the current state (one half of the bin's record)
-    uint32_t *other;    // the other half: the successor state when next_ok
+    uint32_t *rec;      // the bin's record
+    uint32_t *mt;       // the current state: rec + kMtRaw + par * 624
     uint32_t *buf;      // this lane's column of the output buffer
     int idx;            // next state word to temper (0..624)
     int have, pos;      // buffered outputs, next one to hand out
-    bool carried;       // the buffer holds carried-over outputs (not re-derivable from idx)
     uint32_t par, next_ok;
     __device__ void twist() {
+        idx = 0;
         if (next_ok) {  // a fast refill's pretwist kernel has already made the successor
-            uint32_t *t = mt;
-            mt = other;
-            other = t;
             par ^= 1u;
+            mt = rec + kMtRaw + par * kMtHalf;
             next_ok = 0u;
-            idx = 0;
             return;
         }
-        for (int k0 = 0; k0 < 624; k0 += 16) {
+        for (int k0 = 0; k0 < 624; k0 += 16) {          // in place, sixteen words per round of loads
             uint32_t cur[17], far[16];
 #pragma unroll
             for (int q = 0; q < 17; ++q) {
@@ -735,15 +839,16 @@ struct BufferedMT {
                 const int k = k0 + q;
                 if (k < 624) {
                     const uint32_t y = (cur[q] & 0x80000000u) | (cur[q + 1] & 0x7fffffffu);
-                    mt[k] = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    const uint32_t nw = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    mt[k] = nw;                          // and its output, for the fast pipeline's readers
+                    rec[kMtOut + par * kMtHalf + k] = mt_temper(nw);
+                    if (par == 0u && k < kMtMirrorLen) rec[kMtMirror + k] = mt_temper(nw);
                 }
             }
         }
-        idx = 0;
     }
     __device__ uint32_t u32() {
         if (pos >= have) {
-            carried = false;
             if (idx >= 624) twist();
             const int n = 624 - idx < kStreamRngBuf ? 624 - idx : kStreamRngBuf;
             uint32_t y[kStreamRngBuf];
@@ -765,12 +870,11 @@ __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= s.num_envs) return;
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
-    StridedMT rng{rec, 1, 624};          // into the first half
+    StridedMT rng{rec + kMtRaw, 1, 624};     // into the first half; a freshly seeded state has no unused output (index 624)
     rng.seed(s.seed0 + (uint64_t)(s.env_id_base + e));
-    rec[kMtIdx] = (uint32_t)rng.idx;
+    rec[kMtPos] = (uint32_t)rng.idx;
     rec[kMtPar] = 0u;
     rec[kMtNextOk] = 0u;
-    rec[kMtLeftN] = 0u;
     s.gen_next[e] = 0;
 }
 
@@ -788,9 +892,8 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
     if (g >= cur + D) return;
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
     const uint32_t par0 = rec[kMtPar];
-    BufferedMT rng{rec + par0 * kMtHalf, rec + (par0 ^ 1u) * kMtHalf, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
-                   (int)rec[kMtIdx], (int)rec[kMtLeftN], 0, true, par0, rec[kMtNextOk]};
-    for (int q = 0; q < rng.have; ++q) rng.buf[q * kStreamLanes] = rec[kMtLeft + q];
+    BufferedMT rng{rec, rec + kMtRaw + par0 * kMtHalf, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
+                   (int)rec[kMtPos], 0, 0, par0, rec[kMtNextOk]};
     LdsWork work{lds + lane, (CutBox *)s.work + e, (size_t)E};
     const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
     int over = 0;
@@ -804,15 +907,7 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
         for (int t = nw; t < T; ++t) row[t] = term;                        // pad with the terminator (last entry always)
         ++g;
     }
-    // unused outputs: carried-over ones stay in the record, fresh ones are returned by stepping the index back
-    const int left = rng.have - rng.pos;
-    if (rng.carried) {
-        rec[kMtLeftN] = (uint32_t)left;
-        for (int q = 0; q < left; ++q) rec[kMtLeft + q] = rng.buf[(rng.pos + q) * kStreamLanes];
-    } else {
-        rec[kMtLeftN] = 0u;
-        rec[kMtIdx] = (uint32_t)(rng.idx - left);
-    }
+    rec[kMtPos] = (uint32_t)(rng.idx - (rng.have - rng.pos));             // buffered but unused outputs are handed out again
     rec[kMtPar] = rng.par;
     rec[kMtNextOk] = rng.next_ok;
     s.gen_next[e] = g;
