@@ -2391,10 +2391,10 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
         }
         (void)hipEventRecord(side->stepped, main);
         (void)hipStreamWaitEvent(side->stream, side->stepped, 0);
-        // beside the lock-steps a short refill matters more than a full ring: two sequences per bin and refill (the
-        // average bin uses refill_every / 9), more only for a bin that would otherwise run out before the refill after
-        // the next one is complete
-        rc = stream_refill(s, side->stream, 2, 2 * refill_every + 3);
+        // beside the lock-steps a short refill matters more than a full ring: a bin gets about twice what the average
+        // bin uses in refill_every lock-steps (one sequence per ~9), more only if it would otherwise run out before the
+        // refill after the next one is complete
+        rc = stream_refill(s, side->stream, refill_every < 7 ? 2 : (refill_every + 5) / 6, 2 * refill_every + 3);
         (void)hipEventRecord(side->refilled[chunk & 1], side->stream);
     }
     if (side) {     // everything enqueued on `stream` after this call sees the refilled ring

@@ -706,6 +706,11 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     }
 }
 
+// One wave per rewritten row: stable counting sort of the cut boxes by the height of their base (depart_box, :137-138),
+// sort key stripped, the rest of the row padded with the terminator.  Rows of at most 64 boxes (every 10^3 row: 47 at
+// most) never touch LDS: a lane holds one box, its place is the number of boxes with a lower base plus the number of
+// equal ones in lower lanes, counted with one ballot per distinct base height; the next row's boxes are loaded before
+// the current row is ranked.  Longer rows are staged in LDS and ranked chunk by chunk.
 __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWork w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,55 +719,88 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
     int *lvl = (int *)(ent + T);                      // per base height: count, then first free position
     const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const int nrows = w.hdr[3];
-    for (int q = blockIdx.x * 4 + wave; q < nrows; q += gridDim.x * 4) {     // wave-uniform
-        const int64_t id = w.rows[q];
-        const int e = (int)(uint32_t)id, g = (int)(id >> 32);
-        uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
-        const int nv = (int)row[T - 1];
-        wave_sync();
-        for (int k = lane; k < 256; k += 64) lvl[k] = 0;
-        for (int k = lane; k < nv; k += 64) ent[k] = row[k];
-        wave_sync();
-        for (int k = lane; k < nv; k += 64) atomicAdd(&lvl[ent[k] >> 24], 1);
-        wave_sync();
-        {   // exclusive prefix over the 256 levels, four per lane
-            const int c0 = lvl[4 * lane], c1 = lvl[4 * lane + 1], c2 = lvl[4 * lane + 2], c3 = lvl[4 * lane + 3];
-            int incl = c0 + c1 + c2 + c3;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            const int ex = incl - (c0 + c1 + c2 + c3);
-            wave_sync();
-            lvl[4 * lane] = ex;
-            lvl[4 * lane + 1] = ex + c0;
-            lvl[4 * lane + 2] = ex + c0 + c1;
-            lvl[4 * lane + 3] = ex + c0 + c1 + c2;
+    const int nrows = w.hdr[3], stride = gridDim.x * 4;
+    int q = blockIdx.x * 4 + wave;                    // wave-uniform
+    if (q >= nrows) return;
+    auto row_of = [&](int k) {
+        const int64_t id = w.rows[k];
+        return (uint32_t *)s.ring + ((size_t)((int)(id >> 32) % D) * E + (int)(uint32_t)id) * T;
+    };
+    uint32_t *row = row_of(q);
+    uint32_t mine = lane < T - 1 ? row[lane] : 0u;    // this lane's box if the row is short, and the row's length
+    int nv = (int)row[T - 1];
+    for (;;) {
+        const int qn = q + stride;
+        uint32_t *rown = row;
+        uint32_t minen = 0;
+        int nvn = 0;
+        if (qn < nrows) {                             // next row: loads in flight while this one is ranked
+            rown = row_of(qn);
+            minen = lane < T - 1 ? rown[lane] : 0u;
+            nvn = (int)rown[T - 1];
         }
-        wave_sync();
-        for (int k0 = 0; k0 < nv; k0 += 64) {         // stable: chunks in order, lanes in order within a level
-            const int k = k0 + lane;
-            const bool valid = k < nv;
-            const uint32_t val = valid ? ent[k] : 0u;
-            const uint32_t key = val >> 24;
-            int dest = 0;
+        if (nv <= 64) {
+            const bool valid = lane < nv;
+            const uint32_t key = mine >> 24;
+            int place = 0;
             uint64_t todo = __ballot(valid);
-            while (todo) {
+            while (todo) {                            // wave-uniform: one round per distinct base height
                 const int l0 = __ffsll((unsigned long long)todo) - 1;
                 const uint32_t lv = __builtin_amdgcn_readlane(key, l0);
                 const uint64_t m = __ballot(valid && key == lv);
-                const int first = lvl[lv];
-                if (valid && key == lv) dest = first + __popcll(m & below);
-                wave_sync();
-                if (lane == l0) lvl[lv] = first + __popcll(m);
-                wave_sync();
+                place += key > lv ? __popcll(m) : (key == lv ? __popcll(m & below) : 0);
                 todo &= ~m;
             }
-            if (valid) row[dest] = val & 0x00ffffffu;
+            if (valid) row[place] = mine & 0x00ffffffu;
+        } else {
+            wave_sync();
+            for (int k = lane; k < 256; k += 64) lvl[k] = 0;
+            for (int k = lane; k < nv; k += 64) ent[k] = row[k];
+            wave_sync();
+            for (int k = lane; k < nv; k += 64) atomicAdd(&lvl[ent[k] >> 24], 1);
+            wave_sync();
+            {   // exclusive prefix over the 256 levels, four per lane
+                const int c0 = lvl[4 * lane], c1 = lvl[4 * lane + 1], c2 = lvl[4 * lane + 2], c3 = lvl[4 * lane + 3];
+                int incl = c0 + c1 + c2 + c3;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                const int ex = incl - (c0 + c1 + c2 + c3);
+                wave_sync();
+                lvl[4 * lane] = ex;
+                lvl[4 * lane + 1] = ex + c0;
+                lvl[4 * lane + 2] = ex + c0 + c1;
+                lvl[4 * lane + 3] = ex + c0 + c1 + c2;
+            }
+            wave_sync();
+            for (int k0 = 0; k0 < nv; k0 += 64) {     // stable: chunks in order, lanes in order within a level
+                const int k = k0 + lane;
+                const bool valid = k < nv;
+                const uint32_t val = valid ? ent[k] : 0u;
+                const uint32_t key = val >> 24;
+                int dest = 0;
+                uint64_t todo = __ballot(valid);
+                while (todo) {
+                    const int l0 = __ffsll((unsigned long long)todo) - 1;
+                    const uint32_t lv = __builtin_amdgcn_readlane(key, l0);
+                    const uint64_t m = __ballot(valid && key == lv);
+                    const int first = lvl[lv];
+                    if (valid && key == lv) dest = first + __popcll(m & below);
+                    wave_sync();
+                    if (lane == l0) lvl[lv] = first + __popcll(m);
+                    wave_sync();
+                    todo &= ~m;
+                }
+                if (valid) row[dest] = val & 0x00ffffffu;
+            }
         }
         for (int k = nv + lane; k < T; k += 64) row[k] = term;
-        wave_sync();
+        if (qn >= nrows) break;
+        q = qn;
+        row = rown;
+        mine = minen;
+        nv = nvn;
     }
 }
 
