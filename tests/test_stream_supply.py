@@ -39,7 +39,11 @@ class EmuStreamEnv(object):
                                                                   # (at most two sequences per bin and refill unless urgent)
                                                                   ((10, 10, 10), False, 70, 50, 9, 3, True),
                                                                   ((10, 10, 10), True, 40, 64, 20, 8, True),
-                                                                  ((20, 20, 20), False, 5, 30, 9, 3, True)])
+                                                                  ((20, 20, 20), False, 5, 30, 9, 3, True),
+                                                                  # a bin that holds two or three items: episodes shorter than
+                                                                  # the refill interval, bins fall behind and become urgent
+                                                                  ((6, 6, 6), False, 70, 60, 19, 6, True),
+                                                                  ((6, 6, 6), True, 33, 45, 24, 8, True)])
 def test_emulated_stream_supply_matches_oracle_and_python_random(emu, oracle, size, rot, E, steps, depth, refill, native):
     spec_check(lambda sz, r, n, base, spec: EmuStreamEnv(emu, sz, r, n, base, spec), oracle, size, rot, E, steps, depth, refill, native)
 
@@ -167,7 +171,9 @@ def test_emulated_refill_after_many_episodes_without_refill(emu, oracle):
 @pytest.mark.parametrize("size,rot,E,steps,depth,refill,native", [((10, 10, 10), False, 4099, 120, 8, 5, False),
                                                                   ((10, 10, 10), True, 2000, 300, 8, 5, True),
                                                                   ((10, 10, 10), False, 65536, 60, 8, 5, True),
-                                                                  ((20, 20, 20), False, 300, 400, 6, 3, True)])
+                                                                  ((20, 20, 20), False, 300, 400, 6, 3, True),
+                                                                  ((6, 6, 6), False, 5000, 200, 19, 6, True),
+                                                                  ((10, 10, 10), False, 20000, 150, 32, 14, True)])
 def test_gpu_stream_supply_matches_oracle_and_python_random(oracle, size, rot, E, steps, depth, refill, native):
     import torch
     import bpp_amd
