@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--stream", action="store_true",
                     help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
                          "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
-    ap.add_argument("--stream-depth", type=int, default=16, help="--stream: ring rows per bin")
-    ap.add_argument("--stream-refill", type=int, default=6,
+    ap.add_argument("--stream-depth", type=int, default=32, help="--stream: ring rows per bin")
+    ap.add_argument("--stream-refill", type=int, default=14,
                     help="--stream: lock-steps between refills (with depth >= 2 * refill + 3 the refills run beside the lock-steps)")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: enough "

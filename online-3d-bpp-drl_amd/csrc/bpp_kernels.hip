@@ -116,6 +116,22 @@ struct Params {
     int64_t env_id_base;
 };
 
+// Episode-statistics slots.  A slot, and the whole 128-byte line it lies in, is only ever touched by ONE XCD: the slot
+// index is built from the hardware XCC id (32 slots per XCD, picked by `k`), not from assumptions about how workgroups are
+// dealt to the XCDs, so the float64 atomics never meet across the eight L2s.  Why: with slots chosen from the workgroup
+// index alone, one full GPU-suite run (of six that day, on one box) lost 0.05 - 0.7 % of these adds in six tests while
+// every other output stayed bit-exact; it never reproduced, so the cause is not established -- this removes the one
+// cross-XCD interaction the kernels had.  (System-scope atomics, carried out at the memory side, were the other candidate:
+// they cost the step kernel 7 us of 28.)
+__device__ __forceinline__ double *stat_slot(double *stats, int k) {
+    const int xcc = (int)__builtin_amdgcn_s_getreg(6164) & 7;     // hwreg(HW_REG_XCC_ID, 0, 4)
+    return stats + 4 * (xcc * (BPP_STATS_SLOTS / 8) + (k & (BPP_STATS_SLOTS / 8 - 1)));
+}
+// Accumulators that every workgroup of a launch adds to (bpp_episode_stats): system scope, i.e. at the memory side.
+__device__ __forceinline__ void stat_add_shared(double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Per-bin record in LDS written by the bin's lane, read by the cell lanes.
 struct __attribute__((aligned(16))) BinRec {
     uint32_t item;   // item shown in the next observation: x | y<<8 | z<<16
@@ -217,7 +233,7 @@ __device__ __forceinline__ void wave_episode_stats(double *stats, int slot, bool
         s3 += __shfl_down(s3, d, kWave);
     }
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        double *a = stats + 4 * (slot & (BPP_STATS_SLOTS - 1));
+        double *a = stat_slot(stats, slot);
         atomicAdd(a + 0, s0);
         atomicAdd(a + 1, s1);
         atomicAdd(a + 2, s2);
@@ -948,7 +964,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     __syncthreads();
     // episode statistics (main.py:159-162): off the other waves' critical path, after the barrier
     if (MODE == kStep && wid == 0 && p.stats && !BPP_ABL(p, 128))
-        wave_episode_stats(p.stats, blockIdx.x, fin, fin_ret, fin_ratio, fin_len);
+        wave_episode_stats(p.stats, blockIdx.x >> 3, fin, fin_ret, fin_ratio, fin_len);
 
     if (MODE == kStep) {
         // ---- phase 2b: every wave applies its bins' placements (space.py:36-46: window := max_h + z),
@@ -1657,10 +1673,10 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const d
         s3 += __shfl_down(s3, d, kWave);
     }
     if ((threadIdx.x & (kWave - 1)) == 0 && s3 != 0.0) {
-        atomicAdd(acc + 0, s0);
-        atomicAdd(acc + 1, s1);
-        atomicAdd(acc + 2, s2);
-        atomicAdd(acc + 3, s3);
+        stat_add_shared(acc + 0, s0);
+        stat_add_shared(acc + 1, s1);
+        stat_add_shared(acc + 2, s2);
+        stat_add_shared(acc + 3, s3);
     }
 }
 

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(bpp_stream s,
             wave_base[k][threadIdx.x] = tot;
             tot += wave_cnt[k][threadIdx.x];
         }
-        const int base = tot ? atomicAdd(&w.hdr[threadIdx.x], tot) : 0;
+        const int base = tot ? __hip_atomic_fetch_add(&w.hdr[threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
         for (int k = 0; k < kScanThreads / 64; ++k) wave_base[k][threadIdx.x] += base;
     }
     __syncthreads();
@@ -422,7 +422,7 @@ __device__ __forceinline__ uint32_t first_below_key(const uint32_t *ring, int fr
 }
 
 // One visit for a lane whose lists are certain to stay inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap): the statement
-// of cut_visit<true> below without divergent branches and without selects on condition codes.  `act` is the lane's
+// of cut_visit_general below without divergent branches and without selects on condition codes.  `act` is the lane's
 // all-ones / zero activity mask; returns the mask "sequence complete".
 __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int cap, const uint32_t *ring, int filled, uint32_t act,
                                                   uint32_t lo, uint32_t hi) {
@@ -497,17 +497,13 @@ __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int
 }
 
 // One visit (mdCreator.py:59-100 benchmark_split and its bookkeeping in gen_benchmark :120-130), or the part of it the
-// lane has outputs for.  `have` = outputs in the ring from c.used on.  SPILL = false: the lists are certain to stay
-// inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap) and the code has no divergent branch: a store that does not apply
-// goes to the lane's dummy word.  SPILL = true: any list length, entries beyond the LDS part in global memory.  Returns
-// true when the sequence is complete.  (`f == 0 ? v <= lo : v < lo`, :71 / :81 / :91, cannot hold: the side was chosen
-// because it exceeds hi, and bpp_stream requires hi >= 2 lo - 1 >= lo; cut2_generate keeps the test.)
-template <bool SPILL>
-__device__ __forceinline__ bool cut_visit(CutLane &c, const PendLists &pend, const uint32_t *ring, int filled, bool active,
-                                          uint32_t lo, uint32_t hi) {
-    uint32_t *col = pend.lds;
-    const int cap = pend.cap, dummy = 2 * cap;
-    const int abase = c.side ? cap : 0, bbase = cap - abase;
+// lane has outputs for, in plain form: any list length (entries beyond the LDS part live in global memory).  `filled` =
+// outputs put into the ring so far.  Returns true when the sequence is complete.  This is the statement
+// cut_visit_lds above is checked against: a wave runs it whenever one of its lanes' lists may leave LDS.
+// (`f == 0 ? v <= lo : v < lo`, :71 / :81 / :91, cannot hold: the side was chosen because it exceeds hi, and bpp_stream
+// requires hi >= 2 lo - 1 >= lo; cut2_generate keeps the test.)
+__device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &pend, const uint32_t *ring, int filled, uint32_t lo,
+                                                  uint32_t hi) {
     const uint32_t bx = c.box & 255u, by = (c.box >> 8) & 255u, bz = (c.box >> 16) & 255u;
     const bool fx = bx > hi, fy = by > hi, fz = bz > hi;                    // :60-66
     const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
@@ -518,74 +514,51 @@ __device__ __forceinline__ bool cut_visit(CutLane &c, const PendLists &pend, con
     uint32_t x1, x2;
     first_below(ring, c.used, st0 ? (nf == 1u ? 31u : 30u) : (uint32_t)__clz((int)c.v), st0 ? nf : c.v, first1, x1);
     const int have1 = min(filled - c.used, kCand);
-    const bool found1 = active & (first1 < have1);
-    c.used += active ? (found1 ? first1 + 1 : have1) : 0;
-    const bool choose = found1 & st0;
-    const int fnew = x1 == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x1 == 1u ? ((fx & fy) ? 1 : 2) : 2);
-    const int f = choose ? fnew : c.f;
-    const uint32_t v = choose ? (fnew == 0 ? bx : (fnew == 1 ? by : bz)) : c.v;
-    // second one: the cut position for a side chosen just now
-    first_below(ring, c.used, (uint32_t)__clz((int)v), v, first2, x2);
-    const int have2 = min(filled - c.used, kCand);
-    const bool found2 = choose & (first2 < have2);
-    c.used += choose ? (found2 ? first2 + 1 : have2) : 0;
-    const bool fin = (found1 & !st0) | found2;                                // the visit is decided
-    const uint32_t r = (found2 ? x2 : x1) + 1u;
-    const bool good = (r >= lo) & (v - r >= lo);                              // :74, :84, :94
-    const bool split = fin & good, failv = fin & !good;
-    const uint32_t sh = 8u * (uint32_t)f, p1 = f == 2 ? v - r : r, p2 = v - p1;
-    const uint32_t rest = c.box & ~(255u << sh);
-    const uint32_t c1 = rest | (p1 << sh);
-    const uint32_t c2 = (rest | (p2 << sh)) + (f == 2 ? p1 << 24 : 0u);      // :97-98: the upper part starts at high - r
-    // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
-    const bool only = nf == 1u;
-    const bool e1 = split & only & (p1 <= hi), e2 = split & only & (p2 <= hi);
-    const bool q1 = split & !e1, q2 = split & !e2;
-    if (e1) c.row[c.nv] = c1;
-    c.nv += e1;
-    if (e2) c.row[c.nv] = c2;
-    c.nv += e2;
-    c.st = fin ? 0 : (choose ? 1 : c.st);
-    c.f = f;
-    c.v = v;
-    bool pass_end;
-    uint32_t next = 0;
-    if (SPILL) {
-        if (failv) pend.set(c.side ^ 1, c.tail_b++, c.box);                   // stays in invalid_box for the next pass
-        if (q1) pend.set(c.side, c.tail_a++, c1);                             // appended: visited later in this pass
-        if (q2) pend.set(c.side, c.tail_a++, c2);
-        c.i += fin;
-        if (split && c.i < c.tail_a) {            // the removal slid the next box under the iterator: not visited in this pass
-            pend.set(c.side ^ 1, c.tail_b++, pend.get(c.side, c.i));
-            ++c.i;
-        }
-        pass_end = fin && c.i >= c.tail_a;
-        if (fin && !pass_end) next = pend.get(c.side, c.i);
-        else if (pass_end && c.tail_b > 0) next = pend.get(c.side ^ 1, 0);
-    } else {
-        col[(failv ? bbase + c.tail_b : dummy) * 64] = c.box;
-        c.tail_b += failv;
-        col[(q1 ? abase + c.tail_a : dummy) * 64] = c1;
-        c.tail_a += q1;
-        col[(q2 ? abase + c.tail_a : dummy) * 64] = c2;
-        c.tail_a += q2;
-        c.i += fin;
-        // the two entries after the visited box (the first is skipped after a split, :124) and the head of the survivors
-        const uint32_t n1 = col[(abase + min(c.i, cap - 1)) * 64], n2 = col[(abase + min(c.i + 1, cap - 1)) * 64];
-        const bool skip = split & (c.i < c.tail_a);
-        col[(skip ? bbase + c.tail_b : dummy) * 64] = n1;
-        c.tail_b += skip;
-        c.i += skip;
-        const uint32_t b0 = col[bbase * 64];
-        pass_end = fin & (c.i >= c.tail_a);
-        next = pass_end ? b0 : (skip ? n2 : n1);
+    const bool found1 = first1 < have1;
+    c.used += found1 ? first1 + 1 : have1;
+    const bool choose = found1 && st0;
+    if (choose) {
+        c.f = x1 == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x1 == 1u ? ((fx && fy) ? 1 : 2) : 2);
+        c.v = c.f == 0 ? bx : (c.f == 1 ? by : bz);
+        c.st = 1;
     }
-    const bool finished = pass_end & (c.tail_b == 0);
-    c.box = fin ? next : c.box;
-    c.side = pass_end ? c.side ^ 1 : c.side;      // end of the `for`: next pass over the survivors, or done
-    c.tail_a = pass_end ? c.tail_b : c.tail_a;
-    c.tail_b = pass_end ? 0 : c.tail_b;
-    c.i = pass_end ? 0 : c.i;
+    // second one: the cut position for a side chosen just now
+    first_below(ring, c.used, (uint32_t)__clz((int)c.v), c.v, first2, x2);
+    const int have2 = min(filled - c.used, kCand);
+    const bool found2 = choose && first2 < have2;
+    if (choose) c.used += found2 ? first2 + 1 : have2;
+    if (!((found1 && !st0) || found2)) return false;                         // the visit is not decided yet
+    const uint32_t r = (found2 ? x2 : x1) + 1u;
+    const bool split = r >= lo && c.v - r >= lo;                              // :74, :84, :94
+    c.st = 0;
+    if (!split) {
+        pend.set(c.side ^ 1, c.tail_b++, c.box);                              // stays in invalid_box for the next pass
+    } else {
+        const uint32_t sh = 8u * (uint32_t)c.f, p1 = c.f == 2 ? c.v - r : r, p2 = c.v - p1;
+        const uint32_t rest = c.box & ~(255u << sh);
+        const uint32_t c1 = rest | (p1 << sh);
+        const uint32_t c2 = (rest | (p2 << sh)) + (c.f == 2 ? p1 << 24 : 0u);   // :97-98: the upper part starts at high - r
+        // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
+        if (nf == 1u && p1 <= hi) c.row[c.nv++] = c1;
+        else pend.set(c.side, c.tail_a++, c1);                                // appended: visited later in this pass
+        if (nf == 1u && p2 <= hi) c.row[c.nv++] = c2;
+        else pend.set(c.side, c.tail_a++, c2);
+    }
+    ++c.i;
+    if (split && c.i < c.tail_a) {                // the removal slid the next box under the iterator: not visited in this pass
+        pend.set(c.side ^ 1, c.tail_b++, pend.get(c.side, c.i));
+        ++c.i;
+    }
+    if (c.i < c.tail_a) {
+        c.box = pend.get(c.side, c.i);
+        return false;
+    }
+    const bool finished = c.tail_b == 0;          // end of the `for`: next pass over the survivors, or done
+    c.side ^= 1;
+    c.tail_a = c.tail_b;
+    c.tail_b = 0;
+    c.i = 0;
+    if (!finished) c.box = pend.get(c.side, 0);
     return finished;
 }
 
@@ -673,7 +646,7 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
         }
         bool finished;
         if (__ballot(active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap))) {   // wave-uniform: a list may leave LDS
-            finished = active ? cut_visit<true>(c, pend, ring, filled, true, lo, hi) : false;
+            finished = active ? cut_visit_general(c, pend, ring, filled, lo, hi) : false;
         } else {
             finished = cut_visit_lds(c, col, cap, ring, filled, active ? ~0u : 0u, lo, hi) != 0u;
         }

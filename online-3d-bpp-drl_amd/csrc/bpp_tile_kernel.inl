@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     }
     // episode statistics (main.py:159-162): the finishing bins' lead lanes add straight into this workgroup's slot
     if (MODE == kStep && wid == 0 && p.stats && fin && !BPP_ABL(p, 128)) {
-        double *a = p.stats + 4 * (blockIdx.x & (BPP_STATS_SLOTS - 1));
+        double *a = stat_slot(p.stats, blockIdx.x >> 3);
         atomicAdd(a + 0, fin_ret);
         atomicAdd(a + 1, fin_ratio);
         atomicAdd(a + 2, (double)fin_len);

@@ -191,6 +191,14 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t se
     }
     return r;
 }
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+static inline uint32_t __builtin_amdgcn_s_getreg(int) { return 0; }   // hardware registers read as 0 here (one XCC)
+template <typename T>
+static inline T __hip_atomic_fetch_add(T *p, T v, int, int) {
+    const T o = *p;
+    *p = o + v;
+    return o;
+}
 static inline double atomicAdd(double *p, double v) {
     const double o = *p;
     *p = o + v;
