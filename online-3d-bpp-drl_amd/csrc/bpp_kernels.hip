@@ -121,7 +121,8 @@ struct Params {
 // dealt to the XCDs, so the float64 atomics never meet across the eight L2s.  Why: with slots chosen from the workgroup
 // index alone, one full GPU-suite run (of six that day, on one box) lost 0.05 - 0.7 % of these adds in six tests while
 // every other output stayed bit-exact; it never reproduced, so the cause is not established -- this removes the one
-// cross-XCD interaction the kernels had.  (System-scope atomics, carried out at the memory side, were the other candidate:
+// cross-XCD interaction the kernels had (a slot used to move to another XCD whenever the dealing offset c (see xcd_block) changed
+// between two launches).  (System-scope atomics, carried out at the memory side, were the other candidate:
 // they cost the step kernel 7 us of 28.)
 __device__ __forceinline__ double *stat_slot(double *stats, int k) {
     const int xcc = (int)__builtin_amdgcn_s_getreg(6164) & 7;     // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -140,10 +141,12 @@ struct __attribute__((aligned(16))) BinRec {
     uint32_t any;    // set to 1 by any feasible candidate
 };
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).
-// Give every XCD one contiguous eighth of the bins so that cache lines shared by neighbouring waves
-// (the small per-bin outputs, the byte heightmaps) are completed inside ONE L2 instead of being written
-// back as partial lines from several.  Bijective for any grid size; affects speed only.
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: block b runs on XCD (b + c) % 8, where the
+// offset c is the same for all blocks of a launch but not always the same from launch to launch (tools/xcc_map.hip,
+// profiles/r03g_xcc_map.jsonl: 7 for a process's first launch, 6 afterwards).  Give every XCD one contiguous eighth of
+// the bins so that cache lines shared by neighbouring waves (the small per-bin outputs, the byte heightmaps) are
+// completed inside ONE L2 instead of being written back as partial lines from several.  Bijective for any grid size;
+// affects speed only.
 __device__ __forceinline__ int xcd_block(int remap) {
     const int b = blockIdx.x, nb = gridDim.x;
     if (!remap || nb < 16) return b;
