@@ -2394,8 +2394,12 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
         return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");
     int rc = 0;
     // With depth >= 2 R + 3 rows per bin the refill that follows a chunk of R lock-steps may run BESIDE the next chunk
-    // (it only rewrites rows of finished episodes; a bin advances by at most R episodes per chunk and a step reads two
-    // rows ahead): it goes to a side stream, and a chunk starts once the refill issued two chunks earlier is complete.
+    // (it only rewrites rows of finished episodes): it goes to a side stream, and a chunk starts once the refill issued two
+    // chunks earlier is complete.  Margin m = rows a bin has from its current episode on when a refill scans it (the
+    // previous refill is complete by then: same stream).  A bin advances by at most R episodes per chunk and a step reads
+    // two rows ahead, so it needs m >= R + 3 to get through the chunk that runs beside the refill and m + need >= 2 R + 3
+    // to get through the one after (this refill complete, the next one running).  The scan guarantees the second
+    // (need >= 2 R + 3 - m, `urgent`), which also gives the first for the next scan: m' >= m + need - R >= R + 3.
     SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + 3) ? side_stream() : nullptr;
     hipStream_t main = (hipStream_t)stream;
     int32_t chunk = 0;
