@@ -45,11 +45,18 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--rotation", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="run the policy under bf16 autocast")
+    ap.add_argument("--stream", action="store_true",
+                    help="endless item supply generated on the device (every bin its own random.Random, nothing replayed) "
+                         "instead of a pool of 4096 sequences")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     size = (10, 10, 10)
-    pool = bpp_amd.sequences.cut2_pool(size, 4096, seed=0)
-    envs = bpp_amd.BppVecEnv(args.envs, size, enable_rotation=args.rotation, pool=pool, device=dev)
+    if args.stream:
+        envs = bpp_amd.BppVecEnv(args.envs, size, enable_rotation=args.rotation, device=dev,
+                                 stream=dict(bound=(2, 5), seed=0, depth=16, refill_every=8))
+    else:
+        pool = bpp_amd.sequences.cut2_pool(size, 4096, seed=0)
+        envs = bpp_amd.BppVecEnv(args.envs, size, enable_rotation=args.rotation, pool=pool, device=dev)
     policy = Actor(10, envs.action_space.n).to(dev).eval()
     obs = envs.reset()
     masks = envs.location_masks

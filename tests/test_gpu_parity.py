@@ -434,10 +434,11 @@ def test_gpu_example_policy_in_the_loop_runs():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "examples", "rollout_with_policy.py"), "--envs", "512",
-                          "--steps", "12", "--rotation"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "policy in the loop" in out.stdout and "episodes" in out.stdout
+    for extra in (["--rotation"], ["--stream"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", "rollout_with_policy.py"), "--envs", "512",
+                              "--steps", "12"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "policy in the loop" in out.stdout and "episodes" in out.stdout
 
 
 @pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
