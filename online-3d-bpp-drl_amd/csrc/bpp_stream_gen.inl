@@ -568,6 +568,10 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     const int lane = threadIdx.x;
     const int E = s.num_envs, T = s.pool_len, D = s.depth, cap = w.cap;
     const uint32_t lo = (uint32_t)s.bound_lo, hi = (uint32_t)s.bound_hi;
+    // This wave is one long dependency chain that uses a fraction of its SIMD's issue slots; beside the step kernel (eight
+    // waves per SIMD that want every slot) it must win the arbitration whenever it can issue, or the refill falls behind
+    // the lock-steps it runs beside.
+    __builtin_amdgcn_s_setprio(3);
     // wave -> (bucket, position): the longest jobs are dispatched first
     const int n3 = w.hdr[2], n2 = w.hdr[1], n1 = w.hdr[0];
     const int w3 = (n3 + 63) >> 6, w2 = (n2 + 63) >> 6, w1 = (n1 + 63) >> 6;
