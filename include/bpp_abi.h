@@ -108,7 +108,7 @@ typedef struct bpp_batch {
  * most one episode per step: refill at least every depth - 3 lock-steps.  Rows are padded with the terminator
  * (W,L,H); a sequence longer than pool_len - 1 is truncated and counted in `overflow` (size pool_len as
  * W*L*H / bound_lo^3 + 1 to make that impossible -- with rows that long, at most 2048 entries, the refill is the
- * three-kernel pipeline scan / cut / sort of csrc/bpp_stream_gen.inl, else one lane per bin).
+ * four-kernel pipeline scan / pretwist / cut / sort of csrc/bpp_stream_gen.inl, else one lane per bin).
  * `mt` and `work` are opaque; bpp_stream_sizes tells how large they must be (both 16-byte aligned).  `mt` is an
  * array of num_envs equal records, one per bin (copy a bin's record together with its ring rows and gen_next to
  * clone its item stream; checkpoint the whole buffer); `work` is scratch between calls. */
@@ -172,8 +172,8 @@ typedef struct bpp_knobs {
                                  10x10 / 20x20 bins that have a compiled tile kernel (bpp_tile_kernel)          */
     int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = by size (1, or 2 / 4
                                  once a launch's outputs exceed the Infinity Cache) */
-    int32_t stream_legacy;    /* bpp_stream_refill: 1 = the one-lane-per-bin refill kernel also where the three-kernel
-                                 pipeline (scan / cut / sort) applies                                          */
+    int32_t stream_legacy;    /* bpp_stream_refill: 1 = the one-lane-per-bin refill kernel also where the four-kernel
+                                 pipeline (scan / pretwist / cut / sort) applies                                          */
     int32_t stream_overlap;   /* bpp_rollout_uniform_stream: 1 (default) = with depth >= 2 * refill_every + 3 the refills
                                  run on a high-priority side stream beside the next refill_every lock-steps, 0 = on
                                  the caller's stream between the lock-steps                                    */
@@ -284,8 +284,11 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
 int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
                         uint64_t step0, int32_t nsteps, void *stream);
 
-/* bpp_rollout_uniform over a ring pool: additionally calls bpp_stream_refill(s) after every `refill_every`
- * lock-steps (1 <= refill_every <= depth - 3). */
+/* bpp_rollout_uniform over a ring pool: additionally refills the ring after every `refill_every` lock-steps
+ * (1 <= refill_every <= depth - 3).  With depth >= 2 * refill_every + 3 (and the stream_overlap knob on) the refills run on
+ * a library-owned high-priority stream BESIDE the following lock-steps (a chunk of lock-steps starts once the refill
+ * issued two chunks earlier is complete); everything enqueued on `stream` after the call sees a full ring, as after
+ * bpp_stream_refill.  Results are the same either way. */
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
                                uint64_t step0, int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream);
 
