@@ -113,11 +113,30 @@ def cpu_baseline(pool, size, rotation, seconds):
         res = pw.map(_cpu_worker, jobs)
     rate = sum(bins * n / dt for n, dt in res)     # every worker measured over its own busy interval
     return {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "single_core_value": single, "reference_python_context": reference_python_context(),
+            "single_core_value": single, "python_port": python_port_baseline(pool, size, rotation, cores, 0.4 * seconds),
+            "reference_python_context": reference_python_context(),
             "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "
                       "%d processes x %d bins for %.1f s each (sum of per-process rates), and %d bins x %d lock-steps "
                       "in %.1f s on one core; same CUT-2 pool and uniform-feasible policy; os.cpu_count()=%s"
                       % (cores, bins, 0.5 * seconds, bins, n1, dt1, os.cpu_count())}
+
+
+def python_port_baseline(pool, size, rotation, cores, seconds):
+    """north_star asks for the reference SubprocVecEnv timed on this box's host cores in this run; the reference tree
+    does not travel to the GPU box, so what is timed here is oracle/ref_port.py: a pure-Python / numpy restatement of one
+    reference worker's step plus the parent's mask loop with the same numpy work per candidate position, one forked
+    process per usable core -- the reference's plumbing with a perfectly parallel mask loop.  Its outputs are pinned to
+    the C oracle (tests/test_ref_port.py); in the build container it runs at 1.02 - 1.10 x the speed of the live
+    reference on the same core (oracle/time_reference.py, profiles/r03o_reference_python_and_port_cpu_here.json)."""
+    try:
+        from oracle import ref_port
+        rate, longest = ref_port.timed_all_cores(pool, size, rotation, seconds, cores)
+        return {"value": rate, "unit": "env steps/s", "cores": cores, "per_core": rate / cores, "kind": "port (Python)",
+                "sample": "oracle/ref_port.py, %d forked workers x 1 bin for %.1f s each; same CUT-2 pool, "
+                          "uniform-feasible policy" % (cores, longest),
+                "speed_vs_live_reference_same_core": "1.02-1.10x (build container, profiles/r03o_reference_python_and_port_cpu_here.json)"}
+    except Exception as e:       # a baseline must never take the bench line down
+        return {"error": repr(e)}
 
 
 def reference_python_context():
@@ -125,10 +144,10 @@ def reference_python_context():
     host throughput was measured in the build container (oracle/time_reference.py) and is carried here as
     labelled context next to the C port's number -- not measured in this run, not on this box."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_reference_python_cpu_here.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03o_reference_python_and_port_cpu_here.json")))
         d = dict(d)
         d["note"] = ("measured in the build container (8 cores), not on this box and not in this run: the reference "
-                     "tree does not travel to the GPU box; profiles/r01_reference_python_cpu_here.json")
+                     "tree does not travel to the GPU box; profiles/r03o_reference_python_and_port_cpu_here.json")
         return d
     except Exception:
         return None

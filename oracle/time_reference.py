@@ -79,10 +79,26 @@ def r2(size, rotation, steps=400):
     return {"env_steps_per_s_per_core": steps / (time.perf_counter() - t0)}
 
 
+def port(size, rotation, seconds=4.0):
+    """oracle/ref_port.py (what bench.py times on the GPU box) on the same pool, policy and core: its speed next to R2's."""
+    import bpp_amd
+    from oracle import ref_port
+    pool = bpp_amd.sequences.cut2_pool(size, 64, seed=0)
+    rows = [[tuple(int(v) for v in it[:3]) for it in s] for s in pool]
+    steps, dt = ref_port.rollout(rows, size, rotation, seconds, seed=1)
+    return {"env_steps_per_s_per_core": steps / dt}
+
+
 if __name__ == "__main__":
     out = {"host_cores": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__,
            "R1_reference_plumbing_rs_16env": r1(),
            "R2_single_core_cut2_10": r2((10, 10, 10), False),
            "R2_single_core_cut2_10_rot": r2((10, 10, 10), True),
-           "R2_single_core_cut2_20": r2((20, 20, 20), False, steps=120)}
+           "R2_single_core_cut2_20": r2((20, 20, 20), False, steps=120),
+           "python_port_single_core_cut2_10": port((10, 10, 10), False),
+           "python_port_single_core_cut2_10_rot": port((10, 10, 10), True),
+           "python_port_single_core_cut2_20": port((20, 20, 20), False)}
+    for k in ("cut2_10", "cut2_10_rot", "cut2_20"):
+        out["port_over_reference_" + k] = round(out["python_port_single_core_" + k]["env_steps_per_s_per_core"]
+                                                / out["R2_single_core_" + k]["env_steps_per_s_per_core"], 3)
     print(json.dumps(out, indent=1))
