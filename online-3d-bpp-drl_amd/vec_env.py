@@ -130,8 +130,10 @@ class BppVecEnv(object):
     stream:         instead of `pool`: dict(bound=(lo, hi), seed=s, depth=D, refill_every=R) -- an endless CUT-2
                     supply generated on the device (include/bpp_abi.h: bpp_stream).  Every bin owns an exact
                     random.Random(seed + global bin id); its k-th episode plays the k-th sequence that stream
-                    yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.  A refill
-                    kernel runs every R <= D - 3 lock-steps (default D = 8, R = 5).
+                    yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.  The ring
+                    is refilled every R <= D - 3 lock-steps (default D = 8, R = 5); `rollout_uniform` runs the
+                    refills beside the lock-steps when D >= 2 R + 3 (e.g. D = 32, R = 14).  Costs 11 KB of
+                    generator state per bin plus D rows of W*L*H / lo^3 + 1 entries.
     """
 
     def __init__(self, num_envs, container_size=(10, 10, 10), enable_rotation=False, pool=None, device="cuda",
@@ -257,7 +259,7 @@ class BppVecEnv(object):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def refill(self):
-        """Streaming supply: cut new sequences for the episodes the bins have consumed (one kernel, no host sync)."""
+        """Streaming supply: cut new sequences for the episodes the bins have consumed (four kernels, no host sync)."""
         if self._stream is None:
             raise RuntimeError("refill() needs a streaming env (stream=dict(...))")
         self._on_device()
