@@ -2265,6 +2265,7 @@ namespace {
 struct SideStream {
     hipStream_t stream;
     hipEvent_t stepped, refilled[2];
+    std::mutex in_use;     // one bpp_rollout_uniform_stream at a time per device: the events are shared
 };
 SideStream *side_stream() {
     static std::mutex mu;
@@ -2402,6 +2403,8 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
     // (need >= 2 R + 3 - m, `urgent`), which also gives the first for the next scan: m' >= m + need - R >= R + 3.
     SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + 3) ? side_stream() : nullptr;
     hipStream_t main = (hipStream_t)stream;
+    std::unique_lock<std::mutex> hold;
+    if (side) hold = std::unique_lock<std::mutex>(side->in_use);
     int32_t chunk = 0;
     for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every, ++chunk) {
         const int32_t n = nsteps - done < refill_every ? nsteps - done : refill_every;
