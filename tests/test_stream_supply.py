@@ -140,13 +140,14 @@ class EmuKnobEnv(object):
 
 @pytest.mark.parametrize("size,E,depth,steps,pattern", [
     ((10, 10, 10), 130, 8, 40, "fast"), ((10, 10, 10), 130, 8, 40, "alternate"), ((10, 10, 10), 67, 5, 30, "thirds"),
+    ((10, 10, 10), 70, 6, 60, "plain"),          # the one-lane-per-bin kernel alone (twists its generators in place)
     ((20, 20, 20), 9, 5, 12, "fast"),            # ~1100 outputs per sequence: every job twists its generator
     ((20, 20, 20), 9, 5, 12, "alternate"),
     ((8, 12, 9), 40, 6, 30, "fast"),
     ((30, 30, 18), 2, 4, 2, "fast"),             # pending lists beyond the LDS part (peak ~120 entries, 80 in LDS)
 ])
 def test_emulated_fast_and_plain_refill_interchangeable(emu, oracle, size, E, depth, steps, pattern):
-    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2}[pattern]
+    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2, "plain": lambda t: 1}[pattern]
     knob_check(lambda sz, n, base, spec: EmuKnobEnv(emu, sz, n, base, spec), oracle,
                lambda **kw: emu.set_knobs(**kw), size, E, depth, steps, pat)
 
@@ -258,12 +259,13 @@ class GpuKnobEnv(object):
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,E,depth,steps,pattern", [
     ((10, 10, 10), 5000, 8, 60, "fast"), ((10, 10, 10), 5000, 8, 60, "alternate"), ((10, 10, 10), 777, 5, 40, "thirds"),
+    ((10, 10, 10), 3000, 6, 120, "plain"),
     ((20, 20, 20), 200, 5, 40, "fast"), ((20, 20, 20), 130, 5, 20, "alternate"), ((8, 12, 9), 300, 6, 40, "fast"),
     ((30, 30, 18), 70, 4, 3, "fast"),
 ])
 def test_gpu_fast_and_plain_refill_interchangeable(oracle, size, E, depth, steps, pattern):
     import bpp_amd
-    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2}[pattern]
+    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "thirds": lambda t: (t // 3) % 2, "plain": lambda t: 1}[pattern]
     knob_check(GpuKnobEnv, oracle, lambda **kw: bpp_amd._lib.set_knobs(**kw), size, E, depth, steps, pat)
 
 
