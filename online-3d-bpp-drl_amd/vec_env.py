@@ -23,7 +23,7 @@ from .spaces import Box, Discrete
 class StepTensors(object):
     """Device-resident result of one lock-step (views of the env's output buffers unless the env was
     built with fresh_outputs=True)."""
-    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs")
+    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs", "_stage")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -47,7 +47,13 @@ class StepTensors(object):
             return dict(reward=self.reward.cpu().numpy().reshape(E), done=self.done.cpu().numpy(),
                         counter=self.counter.cpu().numpy(), ratio=self.ratio.cpu().numpy(),
                         ep_ret=self.ep_ret.cpu().numpy(), ep_len=self.ep_len.cpu().numpy())
-        h = self._small.cpu().numpy()
+        if self._stage is not None:     # page-locked staging buffer of the env (a ring of four: see BppVecEnv._staging)
+            pinned = self._stage()
+            pinned.copy_(self._small, non_blocking=True)
+            torch.cuda.current_stream(self._small.device).synchronize()
+            h = pinned.numpy()
+        else:
+            h = self._small.cpu().numpy()
         o = self._offs
         return dict(reward=h[o["reward"]:o["reward"] + 4 * E].view("<f4"), done=h[o["done"]:o["done"] + E],
                     counter=h[o["counter"]:o["counter"] + 4 * E].view("<i4"),
@@ -247,8 +253,21 @@ class BppVecEnv(object):
                  ep_len=view("ep_len", torch.int32, 4))
         out = _lib.StepOut(*[(b[k].data_ptr() if b[k] is not None else None)
                              for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
-        b["_small"], b["_offs"] = small, offs
+        b["_small"], b["_offs"], b["_stage"] = small, offs, self._staging
         return b, out
+
+    def _staging(self):
+        """Next of four page-locked host buffers for the per-bin scalars of a step (a device->host copy into pageable
+        memory runs at a fraction of the link's speed).  The numpy views `step()` hands out (done, the infos' sources)
+        therefore stay valid for the three following steps -- the reference loop consumes them at once."""
+        ring = getattr(self, "_stage_ring", None)
+        n = self._bufs["_small"].numel() if self._bufs is not None else 0
+        if ring is None or ring[0].numel() != n:
+            ring = self._stage_ring = [torch.empty((n,), dtype=torch.uint8).pin_memory() for _ in range(4)]
+            self._stage_next = 0
+        buf = ring[self._stage_next]
+        self._stage_next = (self._stage_next + 1) % len(ring)
+        return buf
 
     def _buffers(self):
         if self.fresh_outputs or self._bufs is None:
