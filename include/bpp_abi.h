@@ -12,9 +12,11 @@
  *                                                   test infrastructure only (the parity checker).
  *
  * Ownership: the caller allocates and owns every buffer (PyTorch-ROCm tensors in practice); the
- * library never allocates or frees device memory and keeps no global state besides the thread-local
- * last-error string and the launch-shape knobs (bpp_knobs, which never change results).  Kernels are
- * enqueued on `stream` and the calls return without synchronising.
+ * library never allocates or frees device memory.  Process-global state: the thread-local last-error
+ * string, the launch-shape knobs (bpp_knobs, which never change results) and -- only once
+ * bpp_rollout_uniform_stream has run its refills beside the lock-steps -- one high-priority side stream
+ * plus three events per device, created on first use, guarded by a mutex and kept for the life of the
+ * process.  Kernels are enqueued on `stream` and the calls return without synchronising.
  *
  * Error convention: 0 = success; >0 = hipError_t from the runtime; <0 = BPP_E_* below.  A message
  * is available from bpp_last_error().  An infeasible or out-of-range *action* is not an error: it
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 8
+#define BPP_ABI_VERSION 9
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -38,8 +40,6 @@ extern "C" {
 #define BPP_RULE_UTILS 0 /* acktr/utils.py:8-35   check_box -- the mask the ACKTR loop consumes   */
 #define BPP_RULE_SPACE 1 /* envs/bpp0/space.py:111-144 Space.check_box -- the placement rule, also
                             used by PackingGame.get_possible_position (envs/bpp0/bin3D.py:72-93)  */
-
-#define BPP_STATS_SLOTS 256
 
 /* bpp_step action meaning "leave this bin alone" (no reference counterpart: the reference steps its envs one at a
  * time; lookahead searches step a SUBSET of a batch): state, heightmap and Monitor sums stay as
@@ -87,9 +87,12 @@ typedef struct bpp_batch {
                               values as float32), row-major idx = lx*L + ly,
                               envs/bpp0/space.py:22,153-156                                        */
     bpp_env_state *state;  /* [E]                                                                  */
-    double *stats;         /* NULL, or [BPP_STATS_SLOTS][4] episode statistics accumulated by bpp_step
-                              (same four sums as bpp_episode_stats, spread over slots to keep the
-                              float64 atomics uncontended; the reader sums over the slot axis)    */
+    double *ep_acc;        /* NULL, or [E][4] per-bin episode accumulators kept by bpp_step: when bin e
+                              finishes an episode its row gets += (return, final ratio, length, 1) --
+                              a plain read-modify-write by the one lane that owns the bin, no atomics,
+                              so every row is the float64 sum of that bin's episodes in the order it
+                              played them.  bpp_episode_acc_reduce sums the rows in a fixed order: the
+                              four job-level sums (main.py:159-162) are bit-reproducible             */
     int32_t pool_mode;     /* BPP_POOL_STATIC: the row rule above.  BPP_POOL_RING: seq_pool is the ring of a
                               bpp_stream, pool_size = depth * num_envs, episode k of LOCAL bin e plays row
                               (k mod depth) * num_envs + e, refilled by bpp_stream_refill                */
@@ -296,9 +299,19 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
  * finished episode append info['episode']['r'] and info['ratio'] to the logging deques):
  * acc[0] += sum of episode returns, acc[1] += sum of final ratios, acc[2] += sum of episode lengths,
  * acc[3] += number of episodes, over bins with done != 0.  acc: double[4], caller-zeroed; it is the
- * 32-byte record that multi-GPU jobs all-reduce.  Summation order is unspecified. */
+ * 32-byte record that multi-GPU jobs all-reduce.
+ * Summation order (normative, the oracle library follows it, results are bit-reproducible): BPP_REDUCE_LANES = 1024
+ * partial sums, partial r = the contributions of bins r, r + 1024, r + 2048, ... added in ascending order to 0.0 (a
+ * bin that is not done contributes nothing); then for d = 512, 256, ..., 1: partial[r] += partial[r + d] for r < d;
+ * finally acc[k] += partial[0]. */
+#define BPP_REDUCE_LANES 1024
 int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                       int32_t E, double *acc, void *stream);
+
+/* The same four sums from the per-bin accumulators bpp_step keeps (bpp_batch.ep_acc, [E][4]): acc[k] += sum over bins
+ * of ep_acc[e][k] in the order stated above (every row contributes); clear != 0 zeroes the rows afterwards.  One
+ * workgroup: the call is made once per logging interval (main.py:194-207), not per lock-step. */
+int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *stream);
 
 #ifdef __cplusplus
 }

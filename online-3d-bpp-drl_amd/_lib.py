@@ -10,20 +10,22 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "bpp_kernels.hip")
-# BPP_HIP_LIB: load another build of the same library (profiling builds of tools/build_ablation.sh); never a fallback
-LIB = os.environ.get("BPP_HIP_LIB") or os.path.join(CSRC, "libbpp_hip.so")
+# build() only ever writes BUILD_LIB.  BPP_HIP_LIB: LOAD another build of the same library instead (profiling /
+# diagnostic builds of tools/build_ablation.sh, tools/stress_stats.py) -- never built to, never a fallback
+BUILD_LIB = os.path.join(CSRC, "libbpp_hip.so")
+LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
-STATS_SLOTS = 256
+REDUCE_LANES = 1024
 
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce"]
 
 
 class Batch(ctypes.Structure):
@@ -32,7 +34,7 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class Stream(ctypes.Structure):
@@ -70,6 +72,11 @@ def hipcc():
 
 def build(force=False, verbose=False):
     """Compile csrc/bpp_kernels.hip for gfx950 into csrc/libbpp_hip.so (in-tree; no-op when fresh)."""
+    if LIB != BUILD_LIB:        # an explicitly chosen build is loaded as it is
+        if not os.path.exists(LIB):
+            raise RuntimeError("BPP_HIP_LIB=%s does not exist (it is never built implicitly)" % LIB)
+        return LIB
+
     def fresh():
         return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
@@ -124,6 +131,7 @@ def lib():
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_stream_sizes.argtypes = [ctypes.POINTER(Stream), ctypes.POINTER(ctypes.c_int64)]
         L.bpp_stream_init.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]

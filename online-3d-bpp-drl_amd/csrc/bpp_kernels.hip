@@ -95,7 +95,7 @@ struct Params {
     // state
     uint8_t *hmap;   // [E][A] bytes
     bpp_env_state *state;
-    double *stats;  // [BPP_STATS_SLOTS][4] or nullptr
+    double *ep_acc;  // [E][4] per-bin episode accumulators or nullptr
     const int64_t *actions;
     // mask-only inputs
     const float *obs_in;
@@ -116,19 +116,34 @@ struct Params {
     int64_t env_id_base;
 };
 
-// Episode-statistics slots.  A slot, and the whole 128-byte line it lies in, is only ever touched by ONE XCD: the slot
-// index is built from the hardware XCC id (32 slots per XCD, picked by `k`), not from assumptions about how workgroups are
-// dealt to the XCDs, so the float64 atomics never meet across the eight L2s.  Why: with slots chosen from the workgroup
-// index alone, one full GPU-suite run (of six that day, on one box) lost 0.05 - 0.7 % of these adds in six tests while
-// every other output stayed bit-exact; it never reproduced, so the cause is not established -- this removes the one
-// cross-XCD interaction the kernels had (a slot used to move to another XCD whenever the dealing offset c (see xcd_block) changed
-// between two launches).  (System-scope atomics, carried out at the memory side, were the other candidate:
-// they cost the step kernel 7 us of 28.)
-__device__ __forceinline__ double *stat_slot(double *stats, int k) {
-    const int xcc = (int)__builtin_amdgcn_s_getreg(6164) & 7;     // hwreg(HW_REG_XCC_ID, 0, 4)
-    return stats + 4 * (xcc * (BPP_STATS_SLOTS / 8) + (k & (BPP_STATS_SLOTS / 8 - 1)));
+// Episode statistics (main.py:159-162): every bin owns one row [return sum, final-ratio sum, length sum, episodes] of
+// bpp_batch.ep_acc and the lane that decides the bin adds a finished episode to it with a plain read-modify-write.
+// No atomics: a row has exactly one writer per launch, launches on a stream are ordered, so the row is the float64
+// sum of the bin's episodes in the order it played them -- deterministic, whatever the launch shape.  (Rounds 1-2
+// added into 256 shared slots with float64 L2 atomics; one GPU-suite run lost 0.05 - 0.7 % of those adds, cause never
+// established -- tools/stress_stats.py replays that path from a diagnostic build.)  Cost: the rows of the ~11 % of
+// bins that finish in a lock-step are touched, 2 MB for 65 536 bins, resident in L2 / the Infinity Cache.
+__device__ __forceinline__ void episode_acc_add(double *ep_acc, int e, double ret, double ratio, int len) {
+    double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
+    const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+    a[0] = v0 + ret;
+    a[1] = v1 + ratio;
+    a[2] = v2 + (double)len;
+    a[3] = v3 + 1.0;
 }
-// Accumulators that every workgroup of a launch adds to (bpp_episode_stats): system scope, i.e. at the memory side.
+#ifdef BPP_LEGACY_STATS_ATOMICS
+// Diagnostic builds only (tools/stress_stats.py): the slotted float64 atomics of rounds 1-2, slot picked from the
+// workgroup index as in the build that lost adds, accumulated into g_legacy_slots BESIDE the per-bin rows.
+__device__ double g_legacy_slots[256 * 4];
+__device__ __forceinline__ void legacy_stats_add(int k, double ret, double ratio, int len) {
+    double *a = g_legacy_slots + 4 * (k & 255);
+    atomicAdd(a + 0, ret);
+    atomicAdd(a + 1, ratio);
+    atomicAdd(a + 2, (double)len);
+    atomicAdd(a + 3, 1.0);
+}
+#endif
+// Accumulators that every workgroup of a launch adds to: system scope, i.e. at the memory side.
 __device__ __forceinline__ void stat_add_shared(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -220,28 +235,6 @@ __device__ __forceinline__ uint32_t mix32(uint32_t base, uint32_t gid) {
     h *= 0x846CA68Bu;
     h ^= h >> 16;
     return h;
-}
-
-// Episode statistics of bins that finished this step (main.py:159-162), summed over the wave and added
-// to one of BPP_STATS_SLOTS slots with four float64 atomics per wave that saw a finished episode.
-// Must be called by the whole wave; `fin` marks the lanes that carry a finished bin.
-__device__ __forceinline__ void wave_episode_stats(double *stats, int slot, bool fin, double ret, double ratio, int len) {
-    if (__ballot(fin) == 0ull) return;
-    double s0 = fin ? ret : 0.0, s1 = fin ? ratio : 0.0, s2 = fin ? (double)len : 0.0, s3 = fin ? 1.0 : 0.0;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        s0 += __shfl_down(s0, d, kWave);
-        s1 += __shfl_down(s1, d, kWave);
-        s2 += __shfl_down(s2, d, kWave);
-        s3 += __shfl_down(s3, d, kWave);
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        double *a = stat_slot(stats, slot);
-        atomicAdd(a + 0, s0);
-        atomicAdd(a + 1, s1);
-        atomicAdd(a + 2, s2);
-        atomicAdd(a + 3, s3);
-    }
 }
 
 template <bool VEC, int MODE>
@@ -423,7 +416,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
         }
         rec[lane] = r;
     }
-    if (MODE == kStep && p.stats) wave_episode_stats(p.stats, e0 / p.epw, fin, fin_ret, fin_ratio, fin_len);
+    if (MODE == kStep && p.ep_acc && fin) episode_acc_add(p.ep_acc, e0 + lane, fin_ret, fin_ratio, fin_len);
     wave_sync();
 
     if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
@@ -966,8 +959,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
     }
     __syncthreads();
     // episode statistics (main.py:159-162): off the other waves' critical path, after the barrier
-    if (MODE == kStep && wid == 0 && p.stats && !BPP_ABL(p, 128))
-        wave_episode_stats(p.stats, blockIdx.x >> 3, fin, fin_ret, fin_ratio, fin_len);
+    if (MODE == kStep && wid == 0 && p.ep_acc && fin && !BPP_ABL(p, 128))
+        episode_acc_add(p.ep_acc, dec_e, fin_ret, fin_ratio, fin_len);
 
     if (MODE == kStep) {
         // ---- phase 2b: every wave applies its bins' placements (space.py:36-46: window := max_h + z),
@@ -1656,31 +1649,54 @@ __global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, 
     }
 }
 
-// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.stats: grid-stride
-// partial sums, one wave reduction, four float64 atomics per wave that saw a finished episode.
-__global__ __launch_bounds__(256) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
-                                                    const int32_t *ep_len, int E, double *acc) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        const double f = done[e] ? 1.0 : 0.0;
-        s0 += f * ep_ret[e];
-        s1 += f * ratio[e];
-        s2 += f * (double)ep_len[e];
-        s3 += f;
-    }
+// Fixed-order reductions of the episode statistics (include/bpp_abi.h: BPP_REDUCE_LANES partial sums over strided
+// bins, then a binary tree; ONE workgroup, so the order -- and with it every bit of the four float64 sums that
+// multi-GPU jobs all-reduce -- is the same on every run and equals the oracle's).
+__device__ __forceinline__ void reduce_tree_1024(double s0, double s1, double s2, double s3, double *acc) {
+    static __shared__ double part[4][BPP_REDUCE_LANES];
+    const int t = threadIdx.x;
+    part[0][t] = s0;
+    part[1][t] = s1;
+    part[2][t] = s2;
+    part[3][t] = s3;
+    __syncthreads();
+    for (int d = BPP_REDUCE_LANES / 2; d > 0; d >>= 1) {
+        if (t < d) {
 #pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        s0 += __shfl_down(s0, d, kWave);
-        s1 += __shfl_down(s1, d, kWave);
-        s2 += __shfl_down(s2, d, kWave);
-        s3 += __shfl_down(s3, d, kWave);
+            for (int k = 0; k < 4; ++k) part[k][t] = part[k][t] + part[k][t + d];
+        }
+        __syncthreads();
     }
-    if ((threadIdx.x & (kWave - 1)) == 0 && s3 != 0.0) {
-        stat_add_shared(acc + 0, s0);
-        stat_add_shared(acc + 1, s1);
-        stat_add_shared(acc + 2, s2);
-        stat_add_shared(acc + 3, s3);
+    if (t < 4) acc[t] = acc[t] + part[t][0];
+}
+
+// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.ep_acc.
+__global__ __launch_bounds__(BPP_REDUCE_LANES) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
+                                                                 const int32_t *ep_len, int E, double *acc) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int e = threadIdx.x; e < E; e += BPP_REDUCE_LANES)
+        if (done[e]) {
+            s0 = s0 + ep_ret[e];
+            s1 = s1 + ratio[e];
+            s2 = s2 + (double)ep_len[e];
+            s3 = s3 + 1.0;
+        }
+    reduce_tree_1024(s0, s1, s2, s3, acc);
+}
+
+// The same from the per-bin accumulator rows bpp_step keeps (bpp_batch.ep_acc).
+__global__ __launch_bounds__(BPP_REDUCE_LANES) void acc_reduce_kernel(double *ep_acc, int E, double *acc, int clear) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int e = threadIdx.x; e < E; e += BPP_REDUCE_LANES) {
+        double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
+        const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+        s0 = s0 + v0;
+        s1 = s1 + v1;
+        s2 = s2 + v2;
+        s3 = s3 + v3;
+        if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
     }
+    reduce_tree_1024(s0, s1, s2, s3, acc);
 }
 
 thread_local char g_err[256];
@@ -1926,6 +1942,7 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     if (((uintptr_t)b->hmap & 3u) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
         ((uintptr_t)b->seq_pool & 3u))
         return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
+    if ((uintptr_t)b->ep_acc & 31u) return fail(BPP_E_BADARG, "bpp_batch: ep_acc must be 32-byte aligned");
     Params &p = l.p;
     p.P = b->pool_size;
     p.T = b->pool_len;
@@ -1943,7 +1960,7 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.pool = (const uint32_t *)b->seq_pool;
     p.hmap = b->hmap;
     p.state = b->state;
-    p.stats = b->stats;
+    p.ep_acc = b->ep_acc;
     p.obs = out->obs;
     p.mask = out->mask;
     p.reward = out->reward;
@@ -2437,10 +2454,33 @@ int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *r
                       double *acc, void *stream) {
     if (!done || !ep_ret || !ratio || !ep_len || !acc) return fail(BPP_E_BADARG, "bpp_episode_stats: NULL pointer");
     if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_stats: non-positive size");
-    const int blocks = (E + 255) / 256 < 256 ? (E + 255) / 256 : 256;
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, E, acc);
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(BPP_REDUCE_LANES), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, E, acc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
+
+int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *stream) {
+    if (!ep_acc || !acc) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: NULL pointer");
+    if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: non-positive size");
+    if ((uintptr_t)ep_acc & 31u) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: ep_acc must be 32-byte aligned");
+    hipLaunchKernelGGL(acc_reduce_kernel, dim3(1), dim3(BPP_REDUCE_LANES), 0, (hipStream_t)stream, ep_acc, E, acc, clear);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+#ifdef BPP_LEGACY_STATS_ATOMICS
+// diagnostic builds only (tools/stress_stats.py): read (and optionally clear) the slotted-atomics accumulators
+int bpp_debug_legacy_slots(double *host_out, int clear) {
+    if (!host_out) return fail(BPP_E_BADARG, "bpp_debug_legacy_slots: NULL");
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_legacy_slots), 256 * 4 * 8, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol");
+    if (clear) {
+        std::vector<double> z(256 * 4, 0.0);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_legacy_slots), z.data(), z.size() * 8, 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyToSymbol");
+    }
+    return 0;
+}
+#endif
 
 }  // extern "C"

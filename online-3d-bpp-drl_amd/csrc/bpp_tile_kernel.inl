@@ -13,7 +13,7 @@
 //   * the corner-count rule is evaluated on lane masks (scalar and/or), two selects per candidate;
 //   * the uniform-feasible draw of the next action works on the candidate loop's ballots (scalar popcounts,
 //     one mbcnt in the winning pass) instead of re-scanning the LDS mask bytes;
-//   * episode statistics: the (few) finishing lanes add their four values straight into the slot;
+//   * episode statistics: the (few) finishing lanes add their four values to the bin's own accumulator row;
 //   * a wave owns NIT groups of EPW bins and walks them one after the other: all tiles are staged up front (one
 //     latency for all), wave 0 decides ALL bins of the workgroup in one pass behind ONE pair of barriers (so the
 //     other waves idle once per 4*EPW*NIT bins, not once per 4*EPW), and the stores of group i overlap the
@@ -376,6 +376,13 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     BPP_STAMP(p, 4);
     if (MODE == kStep && wid == 0 && dlead) {   // per-bin outputs and the state record, off the other waves' path
         const int e = dec_e;
+        // episode statistics (main.py:159-162): a finished episode is added to the bin's own accumulator row -- plain
+        // read-modify-write by this lane, no atomics (see episode_acc_add); the row's loads are issued first, their
+        // latency overlaps the stores below
+        const bool acc = p.ep_acc != nullptr && fin && !BPP_ABL(p, 128);
+        double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)e, 32);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
         p.counter[e] = out_boxes;
@@ -383,14 +390,15 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
         p.state[e] = st_out;
-    }
-    // episode statistics (main.py:159-162): the finishing bins' lead lanes add straight into this workgroup's slot
-    if (MODE == kStep && wid == 0 && p.stats && fin && !BPP_ABL(p, 128)) {
-        double *a = stat_slot(p.stats, blockIdx.x >> 3);
-        atomicAdd(a + 0, fin_ret);
-        atomicAdd(a + 1, fin_ratio);
-        atomicAdd(a + 2, (double)fin_len);
-        atomicAdd(a + 3, 1.0);
+        if (acc) {
+            ea[0] = a0 + fin_ret;
+            ea[1] = a1 + fin_ratio;
+            ea[2] = a2 + (double)fin_len;
+            ea[3] = a3 + 1.0;
+        }
+#ifdef BPP_LEGACY_STATS_ATOMICS
+        if (fin) legacy_stats_add(blockIdx.x >> 3, fin_ret, fin_ratio, fin_len);
+#endif
     }
 
     // ---- the wave's NIT groups of EPW bins, one after the other ------------------------------------------

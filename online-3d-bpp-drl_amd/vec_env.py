@@ -202,12 +202,13 @@ class BppVecEnv(object):
                                         refill_every=self.refill_every)
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
             self.state = torch.zeros((self.E, 12), dtype=torch.int32, device=dev)  # bpp_env_state[E], 48 B each
-            # episode statistics accumulated inside the step kernel: [slots][return, ratio, length, count]
-            self.stats_slots = torch.zeros((_lib.STATS_SLOTS, 4), dtype=torch.float64, device=dev)
+            # episode statistics kept inside the step kernel, one row per bin: [return sum, final-ratio sum, length
+            # sum, episodes] -- plain read-modify-write by the bin's own lane, reduced in a fixed order on demand
+            self.ep_acc = torch.zeros((self.E, 4), dtype=torch.float64, device=dev)
         self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
                                  pool_rows, pool_len, self.env_id_base, self.env_id_total,
                                  self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr(),
-                                 self.stats_slots.data_ptr(), pool_mode, 0)
+                                 self.ep_acc.data_ptr(), pool_mode, 0)
         self._batch_ref = ctypes.byref(self._batch)
         self._stream = None
         self._since_refill = 0
@@ -415,10 +416,12 @@ class BppVecEnv(object):
 
     def episode_stats(self, reset=False):
         """float64 [4] device tensor: sum of episode returns, sum of final ratios, sum of episode lengths,
-        number of episodes finished since the last reset of the accumulator (main.py:159-162)."""
-        acc = self.stats_slots.sum(0)
-        if reset:
-            self.stats_slots.zero_()
+        number of episodes finished since the last reset of the accumulators (main.py:159-162).  The per-bin rows
+        (`ep_acc` [E,4]) are summed in the fixed order of include/bpp_abi.h: the result is bit-reproducible."""
+        acc = torch.zeros((4,), dtype=torch.float64, device=self.device)
+        self._on_device()
+        _lib.check(self.lib.bpp_episode_acc_reduce(self.ep_acc.data_ptr(), self.E, acc.data_ptr(), int(bool(reset)),
+                                                   self._stream_ptr()))
         return acc
 
     # ------------------------------------------------------------------ lookahead support (SURVEY 8 f4)
@@ -492,9 +495,9 @@ class BppVecEnv(object):
 
     def state_dict(self):
         """Env checkpoint (the reference never checkpoints env state; a handful of tensors here): byte
-        heightmaps, per-bin records, statistics slots and -- so that a loop can resume mid-rollout -- the
+        heightmaps, per-bin records, per-bin episode accumulators and -- so that a loop can resume mid-rollout -- the
         last observation and its mask."""
-        sd = {"hmap": self.hmap.clone(), "state": self.state.clone(), "stats": self.stats_slots.clone(),
+        sd = {"hmap": self.hmap.clone(), "state": self.state.clone(), "ep_acc": self.ep_acc.clone(),
               "first_reset": self._first_reset}
         if self._stream is not None:   # streaming supply: the ring, every bin's generator and its progress
             sd.update(stream_ring=self.pool.clone(), stream_mt=self._mt.clone(), stream_gen_next=self.gen_next.clone(),
@@ -508,8 +511,8 @@ class BppVecEnv(object):
     def load_state_dict(self, sd):
         self.hmap.copy_(sd["hmap"])
         self.state.copy_(sd["state"])
-        if "stats" in sd:
-            self.stats_slots.copy_(sd["stats"])
+        if "ep_acc" in sd:
+            self.ep_acc.copy_(sd["ep_acc"])
         self._first_reset = bool(sd["first_reset"])
         if self._stream is not None:
             if "stream_ring" not in sd:

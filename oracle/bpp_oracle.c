@@ -318,11 +318,12 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         out->ep_len[e] = s->ep_len;
         out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
         out->done[e] = (uint8_t)done;
-        if (done && b->stats) {                         /* main.py:159-162 */
-            b->stats[0] += s->ep_ret;
-            b->stats[1] += out->ratio[e];
-            b->stats[2] += (double)s->ep_len;
-            b->stats[3] += 1.0;
+        if (done && b->ep_acc) {                        /* main.py:159-162: the bin's own accumulator row */
+            double *a = b->ep_acc + 4 * (size_t)e;
+            a[0] += s->ep_ret;
+            a[1] += out->ratio[e];
+            a[2] += (double)s->ep_len;
+            a[3] += 1.0;
         }
         if (done) {                                     /* shmem_vec_env.py:128-129 */
             s->episode += 1;
@@ -412,18 +413,49 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
     return 0;
 }
 
+/* include/bpp_abi.h: for d = 512 .. 1: partial[r] += partial[r + d] (r < d); acc[k] += partial[0] */
+static void reduce_tree(double part[4][BPP_REDUCE_LANES], double *acc) {
+    for (int d = BPP_REDUCE_LANES / 2; d > 0; d >>= 1)
+        for (int r = 0; r < d; ++r)
+            for (int k = 0; k < 4; ++k) part[k][r] += part[k][r + d];
+    for (int k = 0; k < 4; ++k) acc[k] += part[k][0];
+}
+
 int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                       int32_t E, double *acc, void *stream) {
     (void)stream;
     if (!done || !ep_ret || !ratio || !ep_len || !acc) return fail(BPP_E_BADARG, "bpp_episode_stats: NULL pointer");
     if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_stats: non-positive size");
-    for (int e = 0; e < E; ++e)
-        if (done[e]) {                                  /* main.py:159-162 */
-            acc[0] += ep_ret[e];
-            acc[1] += ratio[e];
-            acc[2] += (double)ep_len[e];
-            acc[3] += 1.0;
-        }
+    /* main.py:159-162; summation order as include/bpp_abi.h states it */
+    static double part[4][BPP_REDUCE_LANES];
+    for (int r = 0; r < BPP_REDUCE_LANES; ++r) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int e = r; e < E; e += BPP_REDUCE_LANES)
+            if (done[e]) {
+                s0 += ep_ret[e];
+                s1 += ratio[e];
+                s2 += (double)ep_len[e];
+                s3 += 1.0;
+            }
+        part[0][r] = s0, part[1][r] = s1, part[2][r] = s2, part[3][r] = s3;
+    }
+    reduce_tree(part, acc);
+    return 0;
+}
+
+int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *stream) {
+    (void)stream;
+    if (!ep_acc || !acc) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: NULL pointer");
+    if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: non-positive size");
+    static double part[4][BPP_REDUCE_LANES];
+    for (int r = 0; r < BPP_REDUCE_LANES; ++r) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int e = r; e < E; e += BPP_REDUCE_LANES)
+            for (int k = 0; k < 4; ++k) s[k] += ep_acc[4 * (size_t)e + k];
+        for (int k = 0; k < 4; ++k) part[k][r] = s[k];
+    }
+    reduce_tree(part, acc);
+    if (clear) memset(ep_acc, 0, (size_t)E * 4 * sizeof(double));
     return 0;
 }
 

@@ -27,7 +27,7 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class Stream(ctypes.Structure):
@@ -105,6 +105,7 @@ def lib():
                                                  ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
                                                  ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -149,11 +150,11 @@ class OracleEnv(object):
                         reward=np.zeros(self.E, np.float32), done=np.zeros(self.E, np.uint8),
                         counter=np.zeros(self.E, np.int32), ratio=np.zeros(self.E, np.float64),
                         ep_ret=np.zeros(self.E, np.float64), ep_len=np.zeros(self.E, np.int32))
-        self.stats = np.zeros((256, 4), np.float64)
+        self.ep_acc = _aligned_zeros(self.E * 32).view(np.float64).reshape(self.E, 4)   # per-bin episode accumulators
         self._b = Batch(self.E, self.W, self.L, self.H, self.rotation, int(mask_rule), self.pool.shape[0],
                         self.pool.shape[1], int(env_id_base),
                         int(env_id_total if env_id_total is not None else env_id_base + self.E),
-                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.stats).value,
+                        _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.ep_acc).value,
                         1 if stream is not None else 0, 0)
         if stream is not None:
             E = self.E
@@ -193,6 +194,12 @@ class OracleEnv(object):
         self._first = False
         self._after_steps(1)
         return self.out["obs"].copy(), self.out["mask"].copy()
+
+    def episode_stats(self, reset=False):
+        """float64 [4]: the per-bin accumulators summed in the ABI's fixed order (bpp_episode_acc_reduce)."""
+        acc = np.zeros(4, np.float64)
+        _check(lib().bpp_episode_acc_reduce(_p(self.ep_acc), self.E, _p(acc), int(bool(reset)), None))
+        return acc
 
     def step(self, actions, copy=True):
         a = np.ascontiguousarray(np.asarray(actions).reshape(-1), dtype=np.int64)

@@ -211,25 +211,36 @@ def test_gpu_full_size_properties_and_slices(bpp, oracle, kernel_path, size, rot
 
 
 def test_gpu_fused_episode_stats_and_standalone_kernel(bpp, oracle):
-    """The statistics accumulated inside bpp_step (slotted float64 atomics) and by the stand-alone
-    bpp_episode_stats kernel equal the oracle's sequential sums up to float64 summation order."""
+    """The statistics kept inside bpp_step (per-bin accumulator rows, no atomics, fixed-order reduction) and the
+    stand-alone bpp_episode_stats kernel equal the oracle's sums BIT FOR BIT (include/bpp_abi.h fixes the order)."""
     size, E = (10, 10, 10), 3000
     pool = bpp.sequences.cut2_pool(size, 64, seed=5)
     env = bpp.BppVecEnv(E, size, enable_rotation=True, pool=pool)
     ref = oracle.OracleEnv(pool, size, True, E)
     env.reset(), ref.reset()
     standalone = bpp.EpisodeStats(env.device)
+    acts = []
     for t in range(30):
         a = env.sample_feasible(seed=2, step=t)
         r = env.step_tensors(a)
         standalone.update(r)
-        ref.step(a.cpu().numpy())
+        acts.append(a.cpu().numpy())
+        ref.step(acts[-1])
+    np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)       # every bin's own row
     fused = env.episode_stats().cpu().numpy()
-    want = ref.stats.sum(0)
+    want = ref.episode_stats()
     assert want[3] > 100
-    np.testing.assert_array_equal(fused[2:], want[2:])                 # lengths and counts are exact integers
-    np.testing.assert_allclose(fused[:2], want[:2], rtol=1e-12)
-    np.testing.assert_allclose(standalone.acc.cpu().numpy(), want, rtol=1e-12)
+    np.testing.assert_array_equal(fused, want)
+    assert want[3] == ref.ep_acc[:, 3].sum() and want[2] == ref.ep_acc[:, 2].sum()
+    np.testing.assert_allclose(want[:2], ref.ep_acc[:, :2].sum(0), rtol=1e-12)
+    # the stand-alone kernel reduces the finished bins of every step in the same fixed order
+    acc = np.zeros(4)
+    ref2 = oracle.OracleEnv(pool, size, True, E)
+    ref2.reset()
+    for t in range(30):
+        o = ref2.step(acts[t])
+        oracle.episode_stats(o["done"], o["ep_ret"], o["ratio"], o["ep_len"], acc)
+    np.testing.assert_array_equal(standalone.acc.cpu().numpy(), acc)
     s = bpp.EpisodeStats(env.device).collect(env).summary()
     assert s["episodes"] == int(want[3]) and abs(s["mean_ratio"] - want[1] / want[3]) < 1e-12
     assert float(env.episode_stats().sum()) == 0.0                      # collect() cleared the accumulator
@@ -368,9 +379,9 @@ def test_gpu_long_soak_matches_oracle(bpp, oracle, size, rot, E, steps):
     for f in st.dtype.names:
         if f != "pad":
             np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
-    got, want = env.episode_stats().cpu().numpy(), ref.stats.sum(0)
-    np.testing.assert_array_equal(got[2:], want[2:])
-    np.testing.assert_allclose(got[:2], want[:2], rtol=1e-11)
+    np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
+    got, want = env.episode_stats().cpu().numpy(), ref.episode_stats()
+    np.testing.assert_array_equal(got, want)
     assert want[3] > E * steps / 60
 
 
@@ -512,9 +523,9 @@ def _lockstep_all_bins(bpp, oracle, size, rot, E, base, total, P, steps=12, seed
     for f in st.dtype.names:
         if f != "pad":
             np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
-    got, want = env.episode_stats().cpu().numpy(), ref.stats.sum(0)
-    np.testing.assert_array_equal(got[2:], want[2:])
-    np.testing.assert_allclose(got[:2], want[:2], rtol=1e-11)
+    np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
+    got, want = env.episode_stats().cpu().numpy(), ref.episode_stats()
+    np.testing.assert_array_equal(got, want)
     assert finished > E // 4
 
 

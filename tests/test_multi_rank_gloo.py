@@ -33,7 +33,7 @@ def _rollout(pool, lo, hi, total):
         o = env.step(a)
         mask = o["mask"]
         obs.append(o["obs"])
-    return np.stack(obs), env.stats.sum(0)
+    return np.stack(obs), env.episode_stats()
 
 
 def _worker(rank, world, port, pool, out_dir):
@@ -109,6 +109,10 @@ def test_gpu_two_ranks_of_the_product_equal_one_global_run(tmp_path):
     parts = [np.load(os.path.join(str(tmp_path), "grank%d.npz" % r)) for r in range(world)]
     g_obs, g_acc = _rollout(pool, 0, TOTAL, TOTAL)
     np.testing.assert_array_equal(np.concatenate([p["obs"] for p in parts], axis=1), g_obs)
+    # the all-reduced record is exactly the sum of the shards' fixed-order reductions (two ranks: one float64 add) ...
+    shard_acc = [_rollout(pool, int(p["lo"]), int(p["hi"]), TOTAL)[1] for p in parts]
     for p in parts:
+        np.testing.assert_array_equal(p["acc"], shard_acc[0] + shard_acc[1])
+        # ... and agrees with the single global run up to the association of that last add
         np.testing.assert_array_equal(p["acc"][2:], g_acc[2:])
         np.testing.assert_allclose(p["acc"][:2], g_acc[:2], rtol=1e-12)
