@@ -10,6 +10,7 @@ actions) are resident in HBM.
     python bench.py --gpus 1 --steps 500 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: starts its N ranks itself through torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job env steps/s, plus
 `roofline` (dominant kernel = bpp_step; algorithmic bytes / HIP-event-measured launch duration vs the
@@ -55,8 +56,12 @@ def parse():
     ap.add_argument("--stream-refill", type=int, default=14,
                     help="--stream: lock-steps between refills (with depth >= 2 * refill + 3 the refills run beside the lock-steps)")
     ap.add_argument("--reps", type=int, default=0,
-                    help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: enough "
-                         "repetitions for >= 100 ms of timed work, at most 25, so that a small --steps is not a 1 ms sample)")
+                    help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: as many as "
+                         "it takes for >= 200 ms of timed GPU work, so that a small --steps is not a 1 ms sample)")
+    ap.add_argument("--launcher", choices=("auto", "direct", "spawn"), default="auto",
+                    help="auto: --gpus N > 1 started without torch.distributed.run launches its N ranks itself; spawn: do "
+                         "that for N = 1 as well")
+    ap.add_argument("--no-past-l3", action="store_true", help="skip the rotating-output-sets (HBM-only) leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -169,19 +174,45 @@ def profile_evidence(key):
     return None
 
 
-def limiter(moved_gbs, valu_util):
-    """What the counters say holds the kernel back: the memory side when the bytes it really moves come close to what a
-    copy kernel achieves, the vector ALUs when they are the busier resource."""
-    if moved_gbs is None or valu_util is None:
+def limiter(moved_gbs_past_l3, valu_util):
+    """What holds the kernel back, comparing like with like: the bytes it moves per second PAST the Infinity Cache
+    (rotating output sets: every written byte goes to HBM) against the 6.29 TB/s a copy kernel reaches from HBM, and the
+    vector ALUs' busy fraction from the SQ counters."""
+    if moved_gbs_past_l3 is None or valu_util is None:
         return None
-    mem = moved_gbs / HBM_ACHIEVABLE_GBS
-    return ("hbm: moves %.0f %% of the 6.3 TB/s a copy kernel achieves (VALU pipes %.0f %% busy)" % (100 * mem, 100 * valu_util)
-            if mem >= valu_util else
-            "valu issue: VALU pipes %.0f %% busy (memory side at %.0f %% of the achievable 6.3 TB/s)" % (100 * valu_util, 100 * mem))
+    mem = moved_gbs_past_l3 / HBM_ACHIEVABLE_GBS
+    return ("hbm: past the Infinity Cache the kernel moves %.0f %% of the 6.29 TB/s a copy kernel achieves from HBM (VALU pipes %.0f %% busy)"
+            % (100 * mem, 100 * valu_util) if mem >= valu_util else
+            "valu issue: VALU pipes %.0f %% busy (past the Infinity Cache the memory side runs at %.0f %% of the 6.29 TB/s copy rate)"
+            % (100 * valu_util, 100 * mem))
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run: start the N ranks ourselves (one process per
+    GPU, the launcher the task statement names) and hand its exit code back.  Rank 0 of the children prints the JSON."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, BPP_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    spawned = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not spawned and (args.gpus > 1 or args.launcher == "spawn"):
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     import bpp_amd
@@ -190,14 +221,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world))
     size = tuple(args.size)
     A = size[0] * size[1]
     M = A * (2 if args.rotation else 1)
     E = args.envs
     if args.pool_file:
-        import numpy as np
-        pool = np.load(args.pool_file)["pool"]
+        pool = bpp_amd.sequences.from_dataset(args.pool_file, size)   # .npz ([P][T][4] `pool`) or a reference dataset/*.pt
     else:
         pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)   # identical on every rank (cpu_baseline uses it too)
     cpu_base = None
@@ -212,8 +242,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device")
     # BPP_BENCH_BACKEND=gloo + BPP_BENCH_ONE_DEVICE=1: smoke-test the multi-rank path on a 1-GPU box
     # (all ranks on device 0, gloo instead of RCCL); never set by the driver.
-    backend = os.environ.get("BPP_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
-    dev_index = 0 if os.environ.get("BPP_BENCH_ONE_DEVICE") else local_rank
+    one_device = bool(os.environ.get("BPP_BENCH_ONE_DEVICE"))
+    backend = os.environ.get("BPP_BENCH_BACKEND", "gloo" if one_device else "nccl")       # "nccl" is RCCL on ROCm
+    if not one_device and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible (one rank per GPU)" % (world, torch.cuda.device_count()))
+    dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # BPP_BENCH_FORCE_PG=1: initialise the process group (and run the barrier / stats all-reduce through it) even
@@ -244,76 +277,115 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # warm-up and the timed region are driven by ONE native call each (bpp_rollout_uniform: the same
-    # sample+step launches, enqueued from C instead of from a Python loop)
-    env.rollout_uniform(seed=1, step0=0, nsteps=args.warmup, actions=actions)
+    def all_max(values):
+        """element-wise maximum over ranks of a list of floats (a region takes as long as its slowest rank)"""
+        if world == 1:
+            return list(values)
+        tm = torch.tensor(values, dtype=torch.float64, device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return tm.cpu().tolist()
+
+    # Warm-up and every timed region are driven by ONE native call each: finite pool -> bpp_rollout_uniform_sets
+    # (every lock-step draws the next one's actions inside the step kernel, so a region of K lock-steps is exactly K
+    # launches of the step kernel and nothing else); --stream -> bpp_rollout_uniform_stream (refills included).
+    state = {"t": 0, "primed": False}
+
+    def drive(n, sets=None):
+        if args.stream:
+            env.rollout_uniform(seed=1, step0=state["t"], nsteps=n, actions=actions)
+        else:
+            env.rollout_uniform_sets(1, state["t"], n, actions, sets=sets, resume=state["primed"])
+            state["primed"] = True
+        state["t"] += n
+
+    drive(args.warmup)
     stats.collect(env).all_reduce()   # also loads the few torch kernels the collection uses
     stats.zero_()
     # timed region = EXACTLY K lock-steps: barrier + synchronize, clock, K lock-steps, synchronize, clock (the maximum
-    # over ranks is taken afterwards); repeated `reps` times and the MEDIAN repetition reported, so that a small K is not
-    # a single sub-millisecond sample.  The path's only collective -- the 32-byte statistics all-reduce -- runs inside
-    # the timed region once per logging interval of LOG_INTERVAL lock-steps, the reference's own cadence
-    # (main.py:194-: every log_interval = 10 updates of num_steps = 5 lock-steps).
+    # over ranks is taken afterwards); repeated `reps` times -- as often as it takes for >= 200 ms of timed GPU work,
+    # whatever K is -- and the MEDIAN repetition reported.  The path's only collective -- the 32-byte statistics
+    # all-reduce -- runs inside the timed region once per logging interval of LOG_INTERVAL lock-steps, the reference's
+    # own cadence (main.py:194-: every log_interval = 10 updates of num_steps = 5 lock-steps).
     LOG_INTERVAL = 50
     since_log = [0]
 
-    def timed_region(step0):
+    def timed_region(sets=None, log=True):
         fence()
         t0 = time.perf_counter()
-        env.rollout_uniform(seed=1, step0=step0, nsteps=args.steps, actions=actions)
+        drive(args.steps, sets)
         since_log[0] += args.steps
-        if since_log[0] >= LOG_INTERVAL:
+        if log and since_log[0] >= LOG_INTERVAL:
             stats.collect(env).all_reduce()
             since_log[0] = 0
         torch.cuda.synchronize(device)
         return time.perf_counter() - t0
 
-    first = timed_region(args.warmup)
-    reps = args.reps if args.reps > 0 else max(1, min(25, int(0.1 / max(first, 1e-6)) + 1))
-    if world > 1:   # every rank must run the same number of repetitions
-        rt = torch.tensor([reps], dtype=torch.int64, device=device)
-        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-        reps = int(rt.item())
-    samples = [first] + [timed_region(args.warmup + (r + 1) * args.steps) for r in range(reps - 1)]
-    if world > 1:   # a repetition takes as long as its slowest rank
-        tm = torch.tensor(samples, dtype=torch.float64, device=device)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        samples = tm.cpu().tolist()
+    def repetitions(first, target_s):
+        reps = args.reps if args.reps > 0 else max(3, min(5000, int(target_s / max(first, 1e-6)) + 1))
+        if world > 1:   # every rank must run the same number of repetitions
+            rt = torch.tensor([reps], dtype=torch.int64, device=device)
+            dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+            reps = int(rt.item())
+        return reps
+
+    first = timed_region()
+    reps = repetitions(first, 0.2)
+    samples = all_max([first] + [timed_region() for _ in range(reps - 1)])
     dt = sorted(samples)[len(samples) // 2]
-    done_steps = args.warmup + reps * args.steps
     stats.collect(env).all_reduce()   # whatever finished since the last logging point (outside the timed regions)
+
+    # dominant kernel (bpp_step) launch duration: HIP events on the launch stream around n_ev lock-steps enqueued back
+    # to back by ONE native call -- exactly n_ev launches of the step kernel between the two events
+    n_ev = max(args.steps, 200)
+
+    def event_timed(n, sets=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        e0.record()
+        drive(n, sets)
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / n
+
+    if args.stream:     # refill kernels run between / beside the lock-steps: event pairs around single launches
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(n_ev, 200))]
+        env.sample_feasible(seed=1, step=state["t"], out=actions)
+        for t, (e0, e1) in enumerate(evs):
+            e0.record()
+            lockstep(state["t"] + t)
+            e1.record()
+        torch.cuda.synchronize(device)
+        state["t"] += len(evs)
+        kern_avg_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+    else:
+        kern_avg_ms = sorted(event_timed(n_ev) for _ in range(3))[1]
+
+    # ---- past the Infinity Cache: the same lock-steps writing R rotating output sets (> 1 GB span), so that no output
+    # byte can stay in the 256 MiB L3 -- the HBM-only figure next to the headline (one 133 MB set fits the L3)
+    past = None
+    if not args.stream and not args.no_past_l3:
+        set_bytes = E * (16 * A + 4 * M + 29)
+        R = max(3, int(1.07e9 / set_bytes) + 1)
+        sets = env.output_sets(R)
+        drive(2 * R, sets)
+        f0 = timed_region(sets, log=False)
+        reps_l3 = repetitions(f0, 0.1)
+        s_l3 = all_max([f0] + [timed_region(sets, log=False) for _ in range(reps_l3 - 1)])
+        dt_l3 = sorted(s_l3)[len(s_l3) // 2]
+        kern_l3_ms = sorted(event_timed(n_ev, sets) for _ in range(3))[1]
+        past = {"output_sets": R, "output_span_MB": round(R * set_bytes / 1e6, 1), "reps": reps_l3,
+                "ms_per_step": dt_l3 / args.steps * 1e3, "value": world * E * args.steps / dt_l3, "launch_us": kern_l3_ms * 1e3}
+        del sets
+
     # same K lock-steps driven step by step from Python (what a Python RL loop pays per step)
     fence()
     t1 = time.perf_counter()
-    env.sample_feasible(seed=1, step=done_steps, out=actions)
+    env.sample_feasible(seed=1, step=state["t"], out=actions)
     for t in range(args.steps):
-        lockstep(done_steps + t)
+        lockstep(state["t"] + t)
     fence()
     dt_py = time.perf_counter() - t1
     summary = stats.summary()
-
-    # dominant kernel (bpp_step) launch duration, HIP events on the launch stream, after the timed region: one event
-    # pair around n_ev lock-steps enqueued back to back by ONE native call (each lock-step is one launch of the step
-    # kernel; the call's single 8 us draw of the first action is in there once), so that neither Python nor the events'
-    # own ~2 us sit between two launches.  Event pairs around single launches are kept as `launch_us_event_pairs`.
-    n_ev = min(args.steps, 200)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for t, (e0, e1) in enumerate(evs):
-        e0.record()
-        lockstep(done_steps + args.steps + t)
-        e1.record()
-    torch.cuda.synchronize(device)
-    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    pair_avg_ms = sum(kern_ms) / len(kern_ms)
-    if args.stream:     # refill kernels run between / beside the lock-steps: only the pairs isolate the step kernel
-        kern_avg_ms = pair_avg_ms
-    else:
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b0.record()
-        env.rollout_uniform(seed=1, step0=done_steps + args.steps + n_ev, nsteps=n_ev, actions=actions)
-        b1.record()
-        torch.cuda.synchronize(device)
-        kern_avg_ms = b0.elapsed_time(b1) / n_ev
 
     if rank == 0:
         headline = size == (10, 10, 10) and not args.rotation and E == 65536 and not args.stream
@@ -329,17 +401,22 @@ def main():
         ev = profile_evidence("%dx%dx%d_rot%d_E%d" % (size + (int(args.rotation), E)))
         traffic = ev.get("traffic_bytes") if ev else None
         moved = traffic / (kern_avg_ms * 1e-3) / 1e9 if traffic else None
+        ach_l3 = b_alg * E / (past["launch_us"] * 1e-6) / 1e9 if past else None
+        moved_l3 = traffic / (past["launch_us"] * 1e-6) / 1e9 if past and traffic else None
         out = {
             "metric": metric,
             "value": world * E * args.steps / dt,
             "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "reps": reps, "stats_all_reduce_every_lock_steps": LOG_INTERVAL, "rep_ms_per_step_min_median_max": [min(samples) / args.steps * 1e3, dt / args.steps * 1e3,
-                                                            max(samples) / args.steps * 1e3],
+            "reps": reps, "timed_gpu_work_ms": sum(samples) * 1e3, "stats_all_reduce_every_lock_steps": LOG_INTERVAL,
+            "rep_ms_per_step_min_median_max": [min(samples) / args.steps * 1e3, dt / args.steps * 1e3, max(samples) / args.steps * 1e3],
             "ms_per_step": dt / args.steps * 1e3,
             "python_loop_ms_per_step": dt_py / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
+            # the same lock-steps with the outputs rotated over > 1 GB: nothing stays in the 256 MiB Infinity Cache
+            "value_past_l3": past["value"] if past else None,
+            "past_l3": past,
             "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
                                    % (size + (" + rotation" if args.rotation else "", E)),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
@@ -351,21 +428,29 @@ def main():
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s%s)"
                                    % (world, "RCCL" if backend == "nccl" else backend,
                                       "" if use_pg else ", no process group at 1 rank"),
+                       "launcher": ("self-launched torch.distributed.run" if os.environ.get("BPP_BENCH_CHILD") else
+                                    "torch.distributed.run" if spawned else "direct"),
                        "episodes_finished": summary["episodes"], "mean_ratio": round(summary["mean_ratio"], 4),
                        "mean_episode_length": round(summary["mean_length"], 2)},
-            # `achieved`/`frac`: ALGORITHMIC bytes (int32 heightmaps as in the reference's layout) per
-            # launch / launch duration.  `achieved_moved`/`frac_moved`: the bytes the kernel really moves (PMC
-            # counters; the state is kept as bytes, so fewer than the algorithmic ones) / the same duration -- the
-            # actual HBM bandwidth.  `limiter`: what the SQ counters say bounds the kernel today.
+            # `achieved`/`frac`: ALGORITHMIC bytes (int32 heightmaps as in the reference's layout) per launch /
+            # launch duration with ONE output set (133 MB at the headline size: it stays in the 256 MiB Infinity Cache, so
+            # this figure is L3-assisted).  `frac_past_l3`: the same with the outputs rotated over > 1 GB -- the HBM-only
+            # figure.  `achieved_moved*`: the bytes the kernel really moves per launch (PMC counters at the L2's fabric
+            # side; the state is kept as bytes, so fewer than the algorithmic ones) / the same durations.
             "roofline": {"bound": "hbm", "kernel": "bpp_step (%s)" % bpp_amd._lib.launch_info(E, size, args.rotation)["kernel_name"],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+                         "frac_is": "L3-assisted: one output set (%.0f MB) fits the 256 MiB Infinity Cache; see frac_past_l3"
+                                    % (E * (16 * A + 4 * M + 29) / 1e6),
+                         "achieved_past_l3": ach_l3, "frac_past_l3": (ach_l3 / HBM_PEAK_GBS) if ach_l3 else None,
+                         "launch_us_past_l3": past["launch_us"] if past else None,
+                         "traffic": traffic, "traffic_unit": "bytes per launch between L2 and fabric (rocprofv3 PMC, profiles/hbm_traffic.json)",
+                         "traffic_source": (ev or {}).get("source"),
                          "achieved_moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
-                         "frac_moved_of_achievable": (moved / HBM_ACHIEVABLE_GBS) if moved else None,
+                         "achieved_moved_past_l3": moved_l3, "frac_moved_past_l3": (moved_l3 / HBM_PEAK_GBS) if moved_l3 else None,
+                         "frac_moved_past_l3_of_hbm_copy_rate": (moved_l3 / HBM_ACHIEVABLE_GBS) if moved_l3 else None,
                          "valu_utilisation": (ev or {}).get("valu_utilisation"),
-                         "limiter": limiter(moved, (ev or {}).get("valu_utilisation")),
-                         "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
-                         "launch_us_event_pairs": [kern_ms[0] * 1e3, pair_avg_ms * 1e3]},
+                         "limiter": limiter(moved_l3, (ev or {}).get("valu_utilisation")),
+                         "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

@@ -287,6 +287,16 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
 int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
                         uint64_t step0, int32_t nsteps, void *stream);
 
+/* The same driver writing the outputs of lock-step t into outs[t mod nsets] (nsets >= 1 complete output sets; with
+ * nsets * bytes-per-set beyond the 256 MiB Infinity Cache every output byte really goes to HBM -- bench.py's
+ * `past_l3` leg) and ALWAYS ending with the fused draw, so that on return `actions` holds the draw for lock-step
+ * step0 + nsteps.  flags & BPP_ROLLOUT_CONTINUE: `actions` already holds the draw for step0 (left by the previous
+ * call) -- the call then enqueues exactly nsteps launches of the step kernel and nothing else; without it the first
+ * action is drawn from `first_mask`, the mask of the current observations (as left by bpp_reset / bpp_step). */
+#define BPP_ROLLOUT_CONTINUE 1
+int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
+                             int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream);
+
 /* bpp_rollout_uniform over a ring pool: additionally refills the ring after every `refill_every` lock-steps
  * (1 <= refill_every <= depth - 3).  With depth >= 2 * refill_every + 3 (and the stream_overlap knob on) the refills run on
  * a library-owned high-priority stream BESIDE the following lock-steps (a chunk of lock-steps starts once the refill

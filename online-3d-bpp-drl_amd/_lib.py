@@ -25,7 +25,7 @@ REDUCE_LANES = 1024
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets"]
 
 
 class Batch(ctypes.Structure):
@@ -46,6 +46,7 @@ class Stream(ctypes.Structure):
 
 
 POOL_STATIC, POOL_RING = 0, 1
+ROLLOUT_CONTINUE = 1
 
 
 class StepOut(ctypes.Structure):
@@ -121,6 +122,9 @@ def lib():
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.bpp_rollout_uniform.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_rollout_uniform_sets.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_int32, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]

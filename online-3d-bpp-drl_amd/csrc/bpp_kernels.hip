@@ -2275,6 +2275,29 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
     return rc;
 }
 
+int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
+                             int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream) {
+    if (!b || !outs || !actions || nsets < 1) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: NULL pointer / no output set");
+    if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: negative nsteps");
+    for (int k = 0; k < nsets; ++k)
+        if (!outs[k].mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: every output set needs a mask");
+    if (nsteps == 0) return 0;
+    const int M = b->W * b->L * (1 + b->rotation);
+    int rc = 0;
+    if (!(flags & BPP_ROLLOUT_CONTINUE)) {
+        if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");
+        rc = bpp_sample_feasible(first_mask, actions, b->num_envs, M, b->env_id_base, seed, step0, stream);
+    }
+    for (int t = 0; rc == 0 && t < nsteps; ++t) {
+        bpp_step_out o = outs[t % nsets];
+        o.next_action = actions;           // every lock-step draws the next one's actions, the last one included
+        o.sample_seed = seed;
+        o.sample_step = step0 + (uint64_t)t + 1;
+        rc = bpp_step(b, actions, &o, stream);
+    }
+    return rc;
+}
+
 }  // extern "C"
 
 namespace {

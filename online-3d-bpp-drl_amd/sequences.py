@@ -37,6 +37,36 @@ def check_pool(pool, container_size):
     return pool
 
 
+def from_dataset(path, container_size=(10, 10, 10), terminator=(10, 10, 10), first_index=1):
+    """Pool from a stored trajectory set -- what the reference's LoadBoxCreator plays (envs/bpp0/binCreator.py:42-72,
+    `--load-dataset --data-name cut_2.pt`): `path` is one of the reference's dataset/*.pt files (a torch-saved list of
+    trajectories, each a list of [x, y, z]) or an .npz holding the same trajectories already packed as uint8 [n][T][4]
+    `pool` in file order (tests/golden/cut2_dataset_10.npz = dataset/cut_2.pt).
+
+    LoadBoxCreator semantics kept: `reset()` PRE-increments its index (:54-55), so the first episode plays
+    trajectory 1, not 0 -> pool row r = trajectory (first_index + r) mod n, and a single bin (env_id_total = 1) plays
+    the trajectories in the creator's order; the creator appends [10, 10, 10] to the stored list (:62; cut_2.pt
+    already stores one at the end of every trajectory) and keeps yielding (10, 10, 10) once the list is used up
+    (:69-72) -> rows are padded with `terminator`, literally (10, 10, 10) as in the reference whatever the bin (pass
+    the bin size for a terminator that can never be placed).  Beyond the reference: it raises IndexError after the
+    last trajectory, the pool wraps around."""
+    term = tuple(int(v) for v in terminator)
+    if str(path).endswith(".npz"):
+        pool = check_pool(np.load(path)["pool"], container_size)
+        tail = pool[:, -1, :3]
+        if not (tail == np.asarray(term, dtype=np.uint8)).all():
+            raise ValueError("%s: the last entry of every row must be the terminator %r" % (path, term))
+        return np.ascontiguousarray(np.roll(pool, -int(first_index), axis=0))
+    import torch
+    trajs = torch.load(path, weights_only=False)
+    n = len(trajs)
+    seqs = [[tuple(int(v) for v in it) for it in trajs[(int(first_index) + r) % n]] for r in range(n)]
+    for q in seqs:                   # a stored trailing terminator is the same thing as the padding
+        while q and q[-1] == term:
+            q.pop()
+    return check_pool(pad_pool(seqs, term), container_size)
+
+
 class _Cut(object):
     """A cuboid being cut (identity semantics, like the reference's Box objects)."""
     __slots__ = ("x", "y", "z", "low", "high")

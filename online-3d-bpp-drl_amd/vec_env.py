@@ -369,6 +369,38 @@ class BppVecEnv(object):
                                                 int(step0), int(nsteps), self._stream_ptr()))
         return self._res
 
+    def output_sets(self, n):
+        """`n` complete sets of output buffers for rollout_uniform_sets (lock-step t writes set t mod n)."""
+        return [self._alloc() for _ in range(int(n))]
+
+    def rollout_uniform_sets(self, seed, step0, nsteps, actions, sets=None, resume=False):
+        """bpp_rollout_uniform_sets: like rollout_uniform, but lock-step t writes its outputs into sets[t mod n]
+        (output_sets(n); default: the env's own single set) and the LAST lock-step also draws the next action, so that
+        a following call with resume=True enqueues nothing but its `nsteps` step-kernel launches.  Finite pools only.
+        Returns the StepTensors of the last lock-step."""
+        if self._first_reset:
+            raise RuntimeError("call reset() before rollout_uniform_sets()")
+        if self._stream is not None:
+            raise RuntimeError("rollout_uniform_sets drives finite pools; streaming envs use rollout_uniform")
+        if not self.compute_mask or self.fresh_outputs:
+            raise RuntimeError("rollout_uniform_sets needs compute_mask=True and fresh_outputs=False")
+        if actions.device != self.device or actions.dtype != torch.int64 or actions.numel() != self.E or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous int64 [E] tensor on the env's device")
+        if sets is None:
+            sets = [(self._bufs, self._out)]
+        n = len(sets)
+        outs = (_lib.StepOut * n)(*[o for _, o in sets])
+        first = self.location_masks
+        self._on_device()
+        _lib.check(self.lib.bpp_rollout_uniform_sets(self._batch_ref, outs, n, first.data_ptr() if first is not None else None,
+                                                     actions.data_ptr(), int(seed), int(step0), int(nsteps),
+                                                     _lib.ROLLOUT_CONTINUE if resume else 0, self._stream_ptr()))
+        if nsteps > 0:
+            self._bufs, self._out = sets[(int(nsteps) - 1) % n]
+            self._res = StepTensors(**self._bufs)
+            self.location_masks = self._bufs["mask"]
+        return self._res
+
     def step_async(self, actions):
         self._pending = self.step_tensors(actions)
 

@@ -459,6 +459,27 @@ int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear
     return 0;
 }
 
+int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
+                             int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream) {
+    if (!b || !outs || !actions || nsets < 1) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: NULL pointer / no output set");
+    if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: negative nsteps");
+    int M = b->W * b->L * (1 + b->rotation), rc = 0;
+    if (nsteps == 0) return 0;
+    if (!(flags & BPP_ROLLOUT_CONTINUE)) {
+        if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");
+        rc = bpp_sample_feasible(first_mask, actions, b->num_envs, M, b->env_id_base, seed, step0, stream);
+    }
+    for (int t = 0; rc == 0 && t < nsteps; ++t) {
+        bpp_step_out o = outs[t % nsets];
+        if (!o.mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: every output set needs a mask");
+        o.next_action = NULL;
+        rc = bpp_step(b, actions, &o, stream);
+        if (rc == 0)
+            rc = bpp_sample_feasible(o.mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t + 1, stream);
+    }
+    return rc;
+}
+
 int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
                         uint64_t step0, int32_t nsteps, void *stream) {
     if (!b || !out || !out->mask || !actions) return fail(BPP_E_BADARG, "bpp_rollout_uniform: NULL pointer");

@@ -89,6 +89,9 @@ def lib():
                                           ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.bpp_rollout_uniform.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
                                           ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_rollout_uniform_sets.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_int32, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
@@ -220,6 +223,22 @@ def rollout_uniform(env, seed, step0, nsteps):
     _check(lib().bpp_rollout_uniform(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
                                      int(nsteps), None))
     return env.out, a
+
+
+def rollout_uniform_sets(env, seed, step0, nsteps, nsets, resume=False, actions=None, first_mask=None):
+    """bpp_rollout_uniform_sets on OracleEnv `env`: lock-step t writes output set t mod nsets; returns (list of the
+    sets as dicts of arrays, actions = the draw for lock-step step0 + nsteps)."""
+    E, A, M = env.E, env.A, env.M
+    sets = [dict(obs=np.zeros((E, 4 * A), np.float32), mask=np.zeros((E, M), np.float32), reward=np.zeros(E, np.float32),
+                 done=np.zeros(E, np.uint8), counter=np.zeros(E, np.int32), ratio=np.zeros(E, np.float64),
+                 ep_ret=np.zeros(E, np.float64), ep_len=np.zeros(E, np.int32)) for _ in range(nsets)]
+    outs = (StepOut * nsets)(*[StepOut(*[_p(d[k]).value for k in ("obs", "mask", "reward", "done", "counter", "ratio",
+                                                                    "ep_ret", "ep_len")]) for d in sets])
+    a = np.zeros(E, np.int64) if actions is None else actions
+    fm = env.out["mask"] if first_mask is None else first_mask
+    _check(lib().bpp_rollout_uniform_sets(ctypes.byref(env._b), outs, nsets, _p(fm), _p(a), int(seed), int(step0), int(nsteps),
+                                          1 if resume else 0, None))
+    return sets, a
 
 
 def mask_from_obs(obs, size, rotation, rule=RULE_UTILS):

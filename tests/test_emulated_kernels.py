@@ -102,6 +102,36 @@ def test_emulated_native_driver_and_fused_draw(emu, oracle, variant, size, rot, 
     np.testing.assert_array_equal(env.hmap, ref.hmap)
 
 
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 70), ((20, 20, 20), False, 9), ((7, 13, 8), True, 19)])
+def test_emulated_rollout_over_rotating_output_sets(emu, oracle, variant, size, rot, E):
+    """bpp_rollout_uniform_sets (bench.py's driver: lock-step t writes output set t mod n, every lock-step draws the
+    next one's actions, BPP_ROLLOUT_CONTINUE resumes without a separate draw) == the oracle's statement of it, and ==
+    the plain one-set driver."""
+    from bpp_amd import sequences
+    pool = sequences.cut2_pool(size, 16, seed=4, bound=(2, min(5, min(size) // 2)), native=False)
+    env = emu.EmuEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    one = oracle.OracleEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    env.reset(), ref.reset(), one.reset()
+    ea = ra = None
+    e_last = r_last = None
+    for step0, n, nsets in ((0, 7, 3), (7, 5, 2), (12, 4, 1)):
+        es, ea = emu.rollout_uniform_sets(env, 5, step0, n, nsets, resume=step0 > 0, actions=ea,
+                                          first_mask=e_last["mask"] if e_last else None)
+        rs, ra = oracle.rollout_uniform_sets(ref, 5, step0, n, nsets, resume=step0 > 0, actions=ra,
+                                             first_mask=r_last["mask"] if r_last else None)
+        np.testing.assert_array_equal(ea, ra)
+        for k in range(nsets):
+            for f in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(es[k][f], rs[k][f], err_msg="%s set %d" % (f, k))
+        e_last, r_last = es[(n - 1) % nsets], rs[(n - 1) % nsets]
+    o, _ = oracle.rollout_uniform(one, 5, 0, 16)
+    for f in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+        np.testing.assert_array_equal(r_last[f], o[f], err_msg=f)
+    np.testing.assert_array_equal(env.hmap, one.hmap)
+    np.testing.assert_array_equal(env.ep_acc, one.ep_acc)
+
+
 @pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
 def test_emulated_tuning_knobs_do_not_change_results(emu, epw, wpb):
     emu.set_knobs(bins_per_wave=epw, waves_per_group=wpb, xcd_remap=(epw + wpb) & 1)

@@ -385,6 +385,35 @@ def test_gpu_long_soak_matches_oracle(bpp, oracle, size, rot, E, steps):
     assert want[3] > E * steps / 60
 
 
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1027), ((20, 20, 20), False, 515)])
+def test_gpu_rollout_over_rotating_output_sets(bpp, oracle, size, rot, E):
+    """bpp_rollout_uniform_sets (bench.py's driver, incl. its past-the-Infinity-Cache leg): lock-step t writes output set
+    t mod n, every lock-step draws the next actions in-kernel, resume=True enqueues step kernels only == the oracle."""
+    import torch
+    pool = bpp.sequences.cut2_pool(size, 64, seed=8)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, env_id_base=11, env_id_total=E + 11)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=11, env_id_total=E + 11)
+    env.reset(), ref.reset()
+    actions = torch.empty(E, dtype=torch.int64, device=env.device)
+    ra, r_last, t = None, None, 0
+    for n, nsets in ((7, 3), (5, 2), (9, 1), (6, 4)):
+        sets = env.output_sets(nsets) if nsets > 1 else None
+        r = env.rollout_uniform_sets(5, t, n, actions, sets=sets, resume=t > 0)
+        rs, ra = oracle.rollout_uniform_sets(ref, 5, t, n, nsets, resume=t > 0, actions=ra,
+                                             first_mask=r_last["mask"] if r_last else None)
+        r_last = rs[(n - 1) % nsets]
+        t += n
+        np.testing.assert_array_equal(actions.cpu().numpy(), ra)
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), r_last[k], err_msg=k)
+        if sets is not None:
+            for j in range(min(n, nsets)):
+                np.testing.assert_array_equal(sets[j][0]["mask"].cpu().numpy(), rs[j]["mask"])
+    np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
+    np.testing.assert_array_equal(env.episode_stats().cpu().numpy(), ref.episode_stats())
+
+
 def test_gpu_masks_property_random_geometries(bpp, oracle):
     """Random small geometries / heightmaps / items (incl. items larger than the bin, heights above H):
     both mask kernels' entry points == the oracle for both rules and both rotation settings."""

@@ -50,3 +50,33 @@ def test_cut1_generator_is_rng_exact(size, rot, n):
         mine = sequences.cut1_sequence(size, rng, random.Random(77 + s), rot, np.random.RandomState(77 + s))
         assert mine == ref
         assert sum(x * y * z for x, y, z in mine) == size[0] * size[1] * size[2]
+
+
+@pytest.mark.parametrize("name,size", [("cut_2.pt", (10, 10, 10)), ("rs.pt", (10, 10, 10)), ("cut_1.pt", (10, 10, 10))])
+def test_from_dataset_plays_what_loadboxcreator_plays(name, size):
+    """sequences.from_dataset == the reference's LoadBoxCreator (binCreator.py:42-72): pre-incremented trajectory index,
+    stored + appended [10,10,10], (10,10,10) for ever after; checked by draining the live creator for several resets."""
+    import os
+    ref_shims.install()
+    from envs.bpp0.binCreator import LoadBoxCreator
+    path = os.path.join(ref_shims.REFERENCE_ROOT, "dataset", name)
+    pool = sequences.from_dataset(path, size)
+    T = pool.shape[1]
+    with contextlib.redirect_stdout(io.StringIO()):
+        cr = LoadBoxCreator(path)
+    assert pool.shape[0] == cr.traj_nums
+    for episode in range(5):
+        cr.reset()                                   # index += 1 first: episode 0 plays trajectory 1
+        n = T + 7                                    # well past the end of the stored list
+        got = [tuple(int(v) for v in b) for b in cr.preview(n)]
+        want = [tuple(int(v) for v in pool[episode, min(c, T - 1), :3]) for c in range(n)]
+        assert got == want, (name, episode)
+
+
+def test_from_dataset_npz_fixture_equals_the_reference_file():
+    import os
+    ref_shims.install()
+    a = sequences.from_dataset(os.path.join(ref_shims.REFERENCE_ROOT, "dataset", "cut_2.pt"))
+    b = sequences.from_dataset(os.path.join(os.path.dirname(__file__), "golden", "cut2_dataset_10.npz"))
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (2100, 48, 4)
