@@ -23,7 +23,7 @@ from .spaces import Box, Discrete
 class StepTensors(object):
     """Device-resident result of one lock-step (views of the env's output buffers unless the env was
     built with fresh_outputs=True)."""
-    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs", "_stage")
+    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs", "_stage", "_hot")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -40,20 +40,34 @@ class StepTensors(object):
         environment -- like the reference's PackingGame -- never produces."""
         return torch.ones((self.done.numel(), 1), dtype=torch.float32, device=self.done.device)
 
+    def _to_host(self, nbytes):
+        """The first `nbytes` of the per-bin scalar block as a numpy byte array that the caller OWNS (copied out of the
+        page-locked staging buffer: those are reused round-robin)."""
+        if self._stage is not None:     # page-locked staging buffer of the env: a pageable destination runs at a fraction of the link's speed
+            pinned = self._stage()
+            pinned[:nbytes].copy_(self._small[:nbytes], non_blocking=True)
+            torch.cuda.current_stream(self._small.device).synchronize()
+            return pinned.numpy()[:nbytes].copy()
+        return self._small[:nbytes].cpu().numpy()
+
+    def host_reward_done(self):
+        """(reward float32 [E], done uint8 [E]) with ONE small device->host copy (5 bytes per bin): all the
+        reference-shaped step() needs before anybody looks at `infos`."""
+        E = self.done.numel()
+        if self._small is None:
+            return self.reward.cpu().numpy().reshape(E), self.done.cpu().numpy()
+        o = self._offs
+        h = self._to_host(self._hot)
+        return h[o["reward"]:o["reward"] + 4 * E].view("<f4"), h[o["done"]:o["done"] + E]
+
     def host_scalars(self):
-        """reward, done, counter, ratio, ep_ret, ep_len as numpy arrays with ONE device->host copy."""
+        """reward, done, counter, ratio, ep_ret, ep_len as numpy arrays (owned by the caller) with ONE device->host copy."""
         E = self.done.numel()
         if self._small is None:
             return dict(reward=self.reward.cpu().numpy().reshape(E), done=self.done.cpu().numpy(),
                         counter=self.counter.cpu().numpy(), ratio=self.ratio.cpu().numpy(),
                         ep_ret=self.ep_ret.cpu().numpy(), ep_len=self.ep_len.cpu().numpy())
-        if self._stage is not None:     # page-locked staging buffer of the env (a ring of four: see BppVecEnv._staging)
-            pinned = self._stage()
-            pinned.copy_(self._small, non_blocking=True)
-            torch.cuda.current_stream(self._small.device).synchronize()
-            h = pinned.numpy()
-        else:
-            h = self._small.cpu().numpy()
+        h = self._to_host(self._small.numel())
         o = self._offs
         return dict(reward=h[o["reward"]:o["reward"] + 4 * E].view("<f4"), done=h[o["done"]:o["done"] + E],
                     counter=h[o["counter"]:o["counter"] + 4 * E].view("<i4"),
@@ -63,43 +77,74 @@ class StepTensors(object):
 
 
 class LazyInfos(object):
-    """`infos` of a VecEnv step: behaves like the reference's tuple of E dicts, but the dicts are only
-    built when somebody indexes/iterates (one device->host copy for the whole batch on first use).
-    The ACKTR loop only reads `'episode' in infos[i]`, `infos[i]['episode']['r']`, `infos[i]['ratio']`
-    and `'bad_transition' in info` (main.py:159-162,173)."""
+    """`infos` of a VecEnv step: behaves like the reference's tuple of E dicts, but nothing is fetched or built until
+    somebody looks.  The ACKTR loop only reads `'episode' in infos[i]`, `infos[i]['episode']['r']`,
+    `infos[i]['ratio']` and `'bad_transition' in info` (main.py:159-162,173).
 
-    def __init__(self, env, res, t_now):
+    What moves when: `step()` itself copies reward + done (5 bytes per bin).  The first access to the info of a
+    FINISHED bin gathers (ep_ret, ep_len, ratio, counter) of the finished bins on the device and copies those few
+    rows; the first access to a bin that is still running copies the whole counter / ratio arrays (12 bytes per bin).
+    The device tensors behind this are the step's own outputs: with fresh_outputs=True (make_vec_envs' setting, the
+    reference's semantics) they stay valid for as long as the infos object lives; with shared output buffers
+    (fresh_outputs=False) they are overwritten by the next step, and a late first access raises instead of returning
+    another step's numbers."""
+
+    def __init__(self, env, res, t_now, done=None, serial=None):
         self._env = env
         self._res = res
         self._t = t_now
-        self._host = None
+        self._done = None if done is None else np.asarray(done).astype(bool)
+        self._serial = serial
+        self._fin = None       # {bin: (ep_ret, ep_len, ratio, counter)} of the finished bins
+        self._live = None      # (counter, ratio) arrays of all bins
         self._dicts = None
 
-    def _fetch(self):
-        if self._host is None:
+    def _check_fresh(self):
+        env = self._env
+        if self._serial is not None and not getattr(env, "fresh_outputs", True) and getattr(env, "_serial", self._serial) != self._serial:
+            raise RuntimeError("infos of an earlier step read after the env stepped again: its output buffers are shared "
+                               "(fresh_outputs=False); read infos before the next step or build the env with fresh_outputs=True")
+
+    def _done_mask(self):
+        if self._done is None:
+            self._check_fresh()
+            self._done = self._res.done.cpu().numpy().astype(bool)
+        return self._done
+
+    def _finished(self):
+        if self._fin is None:
+            self._check_fresh()
+            idx = np.flatnonzero(self._done_mask())
             r = self._res
-            if hasattr(r, "host_scalars"):
-                h = dict(r.host_scalars())
-            else:
-                h = dict(done=r.done.cpu().numpy(), counter=r.counter.cpu().numpy(), ratio=r.ratio.cpu().numpy(),
-                         ep_ret=r.ep_ret.cpu().numpy(), ep_len=r.ep_len.cpu().numpy())
-                if getattr(r, "reward", None) is not None:
-                    h["reward"] = r.reward.cpu().numpy().reshape(-1)
-            h["done"] = h["done"].astype(bool)
-            self._host = h
-        return self._host
+            if idx.size and torch.is_tensor(r.ep_ret):
+                it = torch.from_numpy(idx).to(r.ep_ret.device)
+                f64 = torch.stack([r.ep_ret[it], r.ratio[it]]).cpu().numpy()
+                i32 = torch.stack([r.ep_len[it], r.counter[it]]).cpu().numpy()
+            else:       # plain arrays (host tests)
+                f64 = np.stack([r.ep_ret.cpu().numpy()[idx], r.ratio.cpu().numpy()[idx]])
+                i32 = np.stack([r.ep_len.cpu().numpy()[idx], r.counter.cpu().numpy()[idx]])
+            self._fin = {int(e): (float(f64[0, k]), int(i32[0, k]), np.float64(f64[1, k]), int(i32[1, k])) for k, e in enumerate(idx)}
+        return self._fin
+
+    def _running(self):
+        if self._live is None:
+            self._check_fresh()
+            r = self._res
+            self._live = (r.counter.cpu().numpy().copy(), r.ratio.cpu().numpy().copy())
+        return self._live
 
     def __len__(self):
         return self._env.num_envs
 
     def _make(self, i):
-        h = self._fetch()
-        d = {"counter": int(h["counter"][i]), "ratio": np.float64(h["ratio"][i])}
-        if h["done"][i]:
-            d["mask"] = np.ones(shape=self._env.act_len)                       # bin3D.py:111
-            d["episode"] = {"r": round(float(h["ep_ret"][i]), 6), "l": int(h["ep_len"][i]),
-                            "t": round(self._t - self._env._tstart, 6)}        # bench/monitor.py:64
-        return d
+        if self._done_mask()[i]:
+            ep_ret, ep_len, ratio, counter = self._finished()[i]
+            return {"counter": counter, "ratio": ratio,
+                    "mask": np.ones(shape=self._env.act_len),                  # bin3D.py:111
+                    "episode": {"r": round(ep_ret, 6), "l": ep_len,
+                                "t": round(self._t - self._env._tstart, 6)}}   # bench/monitor.py:64
+        counter, ratio = self._running()
+        return {"counter": int(counter[i]), "ratio": np.float64(ratio[i])}
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -118,7 +163,25 @@ class LazyInfos(object):
         return (self[i] for i in range(len(self)))
 
     def done_indices(self):
-        return np.flatnonzero(self._fetch()["done"])
+        return np.flatnonzero(self._done_mask())
+
+
+def copy_bin_records(hmap, state, src, dst, ring=None, mt=None, gen_next=None, depth=None):
+    """Bins `dst` become copies of bins `src` (int64 index tensors on the tensors' device): byte heightmap [E][A] and
+    the 48-byte record as int32 [E][12].  Streaming supply (ring [depth * E][T][4], generator records mt [E][*], gen_next
+    [E]): the copy continues the SOURCE's item stream, so its ring column, generator record and progress are copied
+    too -- and, because a ring row number encodes the bin (row = (episode mod depth) * E + bin, advanced by += E in the
+    step kernels), the copied `seq` is rebased from the source's column to the destination's; without that the copy
+    would go on reading the source's column, which the source's refills overwrite."""
+    hmap[dst] = hmap[src]
+    state[dst] = state[src]
+    if ring is not None:
+        E = state.shape[0]
+        cols = ring.view(int(depth), E, -1)
+        cols[:, dst] = cols[:, src]
+        mt[dst] = mt[src]
+        gen_next[dst] = gen_next[src]
+        state[dst, 7] = state[src, 7] - src.to(state.dtype) + dst.to(state.dtype)     # bpp_env_state.seq
 
 
 class BppVecEnv(object):
@@ -225,6 +288,7 @@ class BppVecEnv(object):
         self._out = None
         self._res = None
         self._first_reset = True
+        self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
         self._tstart = time.time()
         self.location_masks = None
@@ -233,12 +297,14 @@ class BppVecEnv(object):
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         E, dev = self.E, self.device
-        # the six small per-bin outputs live in ONE byte buffer (8-byte aligned slices) so the
-        # reference-shaped step_wait() needs a single device->host copy
-        offs, total = {}, 0
-        for name, width in (("ratio", 8), ("ep_ret", 8), ("reward", 4), ("counter", 4), ("ep_len", 4), ("done", 1)):
+        # the six small per-bin outputs live in ONE byte buffer (8-byte aligned slices); reward and done come first:
+        # that prefix (5 bytes per bin) is all the reference-shaped step_wait() copies to the host
+        offs, total, hot = {}, 0, 0
+        for name, width in (("reward", 4), ("done", 1), ("ratio", 8), ("ep_ret", 8), ("counter", 4), ("ep_len", 4)):
             offs[name] = total
             total += (E * width + 7) // 8 * 8
+            if name == "done":
+                hot = total
         small = torch.empty((total,), dtype=torch.uint8, device=dev)
 
         def view(name, dtype, width):
@@ -254,13 +320,12 @@ class BppVecEnv(object):
                  ep_len=view("ep_len", torch.int32, 4))
         out = _lib.StepOut(*[(b[k].data_ptr() if b[k] is not None else None)
                              for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
-        b["_small"], b["_offs"], b["_stage"] = small, offs, self._staging
+        b["_small"], b["_offs"], b["_stage"], b["_hot"] = small, offs, self._staging, hot
         return b, out
 
     def _staging(self):
         """Next of four page-locked host buffers for the per-bin scalars of a step (a device->host copy into pageable
-        memory runs at a fraction of the link's speed).  The numpy views `step()` hands out (done, the infos' sources)
-        therefore stay valid for the three following steps -- the reference loop consumes them at once."""
+        memory runs at a fraction of the link's speed).  Callers copy what they keep out of it (StepTensors._to_host)."""
         ring = getattr(self, "_stage_ring", None)
         n = self._bufs["_small"].numel() if self._bufs is not None else 0
         if ring is None or ring[0].numel() != n:
@@ -308,6 +373,7 @@ class BppVecEnv(object):
         if self._stream is not None and not self._first_reset:
             self.refill()              # RESET_ADVANCE moves every bin on by one episode
         _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(out), self._stream_ptr()))
+        self._serial += 1
         self._stepped()
         self._first_reset = False
         self._tstart = time.time()
@@ -344,6 +410,7 @@ class BppVecEnv(object):
         rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), self._stream_ptr())
         if rc:
             _lib.check(rc)
+        self._serial += 1
         self._stepped()
         return self._res
 
@@ -359,6 +426,7 @@ class BppVecEnv(object):
         if actions is None:
             actions = torch.empty((self.E,), dtype=torch.int64, device=self.device)
         self._on_device()
+        self._serial += int(nsteps)
         if self._stream is not None:
             self.refill()
             _lib.check(self.lib.bpp_rollout_uniform_stream(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
@@ -392,6 +460,7 @@ class BppVecEnv(object):
         outs = (_lib.StepOut * n)(*[o for _, o in sets])
         first = self.location_masks
         self._on_device()
+        self._serial += int(nsteps)
         _lib.check(self.lib.bpp_rollout_uniform_sets(self._batch_ref, outs, n, first.data_ptr() if first is not None else None,
                                                      actions.data_ptr(), int(seed), int(step0), int(nsteps),
                                                      _lib.ROLLOUT_CONTINUE if resume else 0, self._stream_ptr()))
@@ -409,10 +478,10 @@ class BppVecEnv(object):
         r, self._pending = self._pending, None
         if r is None:
             raise RuntimeError("step_wait() without step_async()")
-        infos = LazyInfos(self, r, time.time())
-        h = infos._fetch()                          # one device->host copy for all per-bin scalars
-        reward = torch.from_numpy(np.array(h["reward"], dtype=np.float32)).unsqueeze(1)  # CPU [E,1], acktr/envs.py:192
-        return r.obs, reward, h["done"], infos
+        rew, done = r.host_reward_done()            # ONE device->host copy: 5 bytes per bin
+        done = done.astype(bool)
+        reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
+        return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
 
     def step(self, actions):
         self.step_async(actions)
@@ -504,13 +573,11 @@ class BppVecEnv(object):
         dst = torch.as_tensor(dst, dtype=torch.int64, device=self.device).reshape(-1)
         if src.numel() != dst.numel():
             raise ValueError("src and dst must have the same length")
-        self.hmap[dst] = self.hmap[src]
-        self.state[dst] = self.state[src]
-        if self._stream is not None:       # the copy continues the source's item stream: ring rows + generator state
-            ring = self.pool.view(self.stream_spec["depth"], self.E, -1)
-            ring[:, dst] = ring[:, src]
-            self._mt[dst] = self._mt[src]
-            self.gen_next[dst] = self.gen_next[src]
+        if self._stream is not None:
+            copy_bin_records(self.hmap, self.state, src, dst, ring=self.pool, mt=self._mt, gen_next=self.gen_next,
+                             depth=self.stream_spec["depth"])
+        else:
+            copy_bin_records(self.hmap, self.state, src, dst)
 
     def preview(self, k):
         """The next `k` items of every bin, int32 [E, k, 3] -- `box_creator.preview(k)`
@@ -533,22 +600,38 @@ class BppVecEnv(object):
               "first_reset": self._first_reset}
         if self._stream is not None:   # streaming supply: the ring, every bin's generator and its progress
             sd.update(stream_ring=self.pool.clone(), stream_mt=self._mt.clone(), stream_gen_next=self.gen_next.clone(),
-                      stream_since_refill=self._since_refill)
+                      stream_since_refill=self._since_refill, stream_spec=self._stream_identity())
         if self._bufs is not None:
             sd["obs"] = self._bufs["obs"].clone()
             if self._bufs["mask"] is not None:
                 sd["mask"] = self._bufs["mask"].clone()
         return sd
 
+    def _stream_identity(self):
+        """What must agree for a streaming checkpoint to continue the same item streams."""
+        sp = self.stream_spec
+        return dict(bound=tuple(sp["bound"]), seed=sp["seed"], depth=sp["depth"], pool_len=sp["pool_len"],
+                    num_envs=self.E, env_id_base=self.env_id_base, bin_size=self.bin_size)
+
     def load_state_dict(self, sd):
+        if self._stream is None and "stream_ring" in sd:
+            raise ValueError("checkpoint of a streaming env loaded into a pool-based env (its ring and generators would be dropped)")
+        if self._stream is not None:
+            if "stream_ring" not in sd:
+                raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
+            want, got = self._stream_identity(), sd.get("stream_spec")
+            if got is not None and dict(got) != want:
+                raise ValueError("checkpoint stream_spec %r does not match this env's %r" % (dict(got), want))
+            if tuple(sd["stream_ring"].shape) != tuple(self.pool.shape) or tuple(sd["stream_mt"].shape) != tuple(self._mt.shape):
+                raise ValueError("checkpoint stream_spec: ring / generator buffers have another shape than this env's")
+        if tuple(sd["hmap"].shape) != tuple(self.hmap.shape):
+            raise ValueError("checkpoint holds %r heightmaps, this env %r" % (tuple(sd["hmap"].shape), tuple(self.hmap.shape)))
         self.hmap.copy_(sd["hmap"])
         self.state.copy_(sd["state"])
         if "ep_acc" in sd:
             self.ep_acc.copy_(sd["ep_acc"])
         self._first_reset = bool(sd["first_reset"])
         if self._stream is not None:
-            if "stream_ring" not in sd:
-                raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
             self.pool.copy_(sd["stream_ring"])
             self._mt.copy_(sd["stream_mt"])
             self.gen_next.copy_(sd["stream_gen_next"])

@@ -168,15 +168,16 @@ static int64_t next_row(const bpp_batch *b, int64_t seq) {
     return (seq + stride) % b->pool_size;
 }
 
-/* BoxCreator.preview(1)[0] (envs/bpp0/binCreator.py:15-18) on the pooled sequence this bin plays. */
+/* BoxCreator.preview(1)[0] (envs/bpp0/binCreator.py:15-18): the item the bin is about to place.  It is read from the
+ * state record (item_cur), which refresh_item_cache() below fills from the pooled sequence after every reset / step --
+ * so it IS the pool entry at (seq, cursor) unless a caller overwrote it in between (BppVecEnv.set_current_items: the
+ * reorder search of acktr/reorder.py:181-215 plays previewed items in another order), exactly what the kernels play. */
 static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item[3]) {
+    (void)b;
     (void)e;
-    int64_t seq = s->seq;
-    int c = s->cursor < b->pool_len ? s->cursor : b->pool_len - 1;
-    const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
-    item[0] = p[0];
-    item[1] = p[1];
-    item[2] = p[2];
+    item[0] = (int)(s->item_cur & 255u);
+    item[1] = (int)((s->item_cur >> 8) & 255u);
+    item[2] = (int)((s->item_cur >> 16) & 255u);
 }
 
 /* Keep the pool-entry cache of the state record coherent (see include/bpp_abi.h). */
@@ -234,8 +235,8 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
         s->episode = mode == BPP_RESET_INIT ? 0 : s->episode + 1;
         reset_bin(b, e, s, mode == BPP_RESET_INIT);
         int item[3];
-        next_box(b, e, s, item);
         refresh_item_cache(b, e, s);
+        next_box(b, e, s, item);
         write_obs_mask(b, e, item, out);
     }
     return 0;
@@ -329,8 +330,8 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
             s->episode += 1;
             reset_bin(b, e, s, 0);
         }
+        refresh_item_cache(b, e, s);                    /* from the pool at the new (seq, cursor) */
         next_box(b, e, s, item);
-        refresh_item_cache(b, e, s);
         write_obs_mask(b, e, item, out);
     }
     if (out->next_action) {

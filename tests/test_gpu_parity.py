@@ -300,6 +300,40 @@ def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
     envs.close()
 
 
+def test_gpu_dropin_infos_read_late_are_still_the_steps_own(bpp):
+    """a loop that collects `infos` over a rollout and reads them afterwards.  With the factory's
+    fresh_outputs=True every infos object keeps describing ITS step (finished and running bins alike, fetched lazily
+    long after later steps ran); with shared output buffers a late first access raises instead of showing another
+    step's numbers."""
+    import types
+    import torch
+    g = load_golden("rollout_cut2_10_rot")
+    E = g["actions"].shape[1]
+    args = types.SimpleNamespace(container_size=(10, 10, 10), enable_rotation=True, data_type="cut2", box_size_set=None)
+    envs = bpp.make_vec_envs("Bpp-v0", 1, E, 1.0, None, "cuda:0", False, args=args, pool=g["pool"])
+    envs.reset()
+    kept = []
+    for t in range(30):
+        _, reward, done, infos = envs.step(torch.from_numpy(g["actions"][t]).unsqueeze(1))
+        kept.append((reward, done, infos))
+    assert sum(int(d.sum()) for _, d, _ in kept) > 0
+    for t, (reward, done, infos) in enumerate(kept):            # nothing was looked at until now
+        np.testing.assert_array_equal(reward.numpy()[:, 0], g["reward"][t])
+        np.testing.assert_array_equal(done, g["done"][t].astype(bool))
+        for e in range(E):
+            i = infos[e]
+            assert i["counter"] == g["counter"][t][e] and i["ratio"] == g["ratio"][t][e], (t, e)
+            if done[e]:
+                assert i["episode"]["r"] == g["ep_r"][t][e] and i["episode"]["l"] == g["ep_l"][t][e]
+    shared = bpp.BppVecEnv(E, (10, 10, 10), enable_rotation=True, pool=g["pool"])       # fresh_outputs=False
+    shared.reset()
+    _, _, _, first = shared.step(torch.from_numpy(g["actions"][0]))
+    _, _, _, second = shared.step(torch.from_numpy(g["actions"][1]))
+    assert second[0]["counter"] == g["counter"][1][0]
+    with pytest.raises(RuntimeError, match="fresh_outputs"):
+        first[0]
+
+
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1000), ((20, 20, 20), False, 301),
                                          ((20, 20, 10), True, 130), ((7, 13, 8), True, 97)])
 def test_gpu_fused_next_action_equals_standalone_sampler(bpp, oracle, kernel_path, size, rot, E):

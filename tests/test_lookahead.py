@@ -208,3 +208,39 @@ def test_gpu_window_masks_and_item_override():
     want = bpp_amd.batched_mask_from_hmap(env.heightmaps()[[4, 9, 30]].reshape(3, -1), items, size, True, "utils")
     assert torch.equal(r.mask[[4, 9, 30]], want)
     assert torch.equal(r.obs[[4, 9, 30]].view(3, 4, 100)[:, 1:, 0], items.float().to(r.obs.device))
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_emulated_reordered_items_match_oracle(emu, oracle, rot):
+    """set_current_items (the reorder search plays previewed items in another order, acktr/reorder.py:181-215)
+    overwrites bpp_env_state.item_cur; both the kernels and -- now -- the oracle play THAT item, then continue the
+    sequence as before.  Subset stepping (BPP_ACTION_NOOP) for the bins that are not being reordered."""
+    from bpp_amd import sequences
+    size, E = (10, 10, 10), 37
+    pool = sequences.cut2_pool(size, 16, seed=9, native=False)
+    envs = [m.OracleEnv(pool, size, rot, E, mask_rule=1) for m in (emu, oracle)]
+    masks = [e.reset()[1] for e in envs]
+    rng = np.random.RandomState(4)
+    T = pool.shape[1]
+    for t in range(14):
+        ids = np.flatnonzero(rng.rand(E) < 0.4)
+        for env in envs:                                 # swap in the item two places ahead (preview(3)[2]) for bins `ids`
+            st = env.state
+            for e in ids:
+                it = pool[int(st["seq"][e]), min(int(st["cursor"][e]) + 2, T - 1)]
+                st["item_cur"][e] = int(it[0]) | (int(it[1]) << 8) | (int(it[2]) << 16)
+        outs = [env.step(np.full(E, NOOP, np.int64)) for env in envs]            # observe(): new observation / mask
+        for k in ("obs", "mask"):
+            np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg="%s observe t=%d" % (k, t))
+        for e in ids:                                    # the overwritten item is what the observation shows
+            st = envs[1].state
+            assert int(outs[1]["obs"][e, 100]) == int(st["item_cur"][e]) & 255
+        a = oracle.sample_feasible(outs[1]["mask"], 3, t)
+        a[rng.rand(E) < 0.3] = NOOP                      # step a subset only
+        outs = [env.step(a) for env in envs]
+        for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg="%s t=%d" % (k, t))
+        for f in ("cursor", "episode", "n_boxes", "vol_sum", "seq", "item_cur", "item_next", "item_reset"):
+            np.testing.assert_array_equal(envs[0].state[f], envs[1].state[f], err_msg=f)
+    np.testing.assert_array_equal(envs[0].hmap, envs[1].hmap)
+    assert envs[1].state["n_boxes"].max() >= 3

@@ -305,3 +305,129 @@ def test_gpu_refill_beside_the_lock_steps_changes_nothing(oracle, size, E, depth
     np.testing.assert_array_equal(results[0]["obs"], o["obs"])
     np.testing.assert_array_equal(results[0]["ring"], ref.pool)
     np.testing.assert_array_equal(results[0]["gen_next"], ref.gen_next)
+
+
+def test_emulated_streaming_clone_continues_the_sources_item_stream(emu):
+    """a bin cloned in streaming mode must keep playing the SOURCE's item stream from its own ring
+    column.  Clone bin 0 into bin 1, let bin 0 fail through more than `depth` episodes (its refills rewrite its column),
+    then play bin 1: it must show exactly the items random.Random(seed + id of bin 0) yields for the episode it was
+    cloned in and the following ones.  Runs the product's own host-side copy (vec_env.copy_bin_records) on the
+    emulated kernels' buffers."""
+    import torch
+    from bpp_amd.vec_env import copy_bin_records
+    size, E, base, seed, depth = (10, 10, 10), 6, 40, 5, 6
+    NOOP = -2 ** 63
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=1)
+    # mask_rule = 1 (Space.check_box): a position the mask shows is one the placement accepts
+    env = emu.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E, stream=spec, mask_rule=1)
+    obs, mask = env.reset()
+    A = 100
+
+    def shown(o, e):
+        return tuple(int(o[e, (p + 1) * A]) for p in range(3))
+
+    # bin 0 places two items, then gets cloned into bin 1
+    for t in range(2):
+        a = emu.sample_feasible(mask, 1, t, env_id_base=base)
+        o = env.step(a)
+        mask = o["mask"]
+    assert not o["done"][0] and int(env.state["cursor"][0]) == 2 and int(env.state["episode"][0]) == 0
+    hm = torch.from_numpy(env.hmap)
+    st = torch.from_numpy(env.state.view(np.int32).reshape(E, 12))
+    ring = torch.from_numpy(env.pool)
+    mt = torch.from_numpy(env._mt.view(np.int32).reshape(E, -1))
+    gn = torch.from_numpy(env.gen_next)
+    copy_bin_records(hm, st, torch.tensor([0]), torch.tensor([1]), ring=ring, mt=mt, gen_next=gn, depth=depth)
+    assert int(env.state["seq"][1]) == int(env.state["seq"][0]) + 1        # same ring row index, the copy's own column
+    # bin 0 fails 2 * depth times in a row (refill after every lock-step rewrites its column); every other bin waits
+    for t in range(2 * depth):
+        a = np.full(E, NOOP, np.int64)
+        a[0] = -1
+        o = env.step(a)
+        assert o["done"][0]
+    assert int(env.state["episode"][0]) == 2 * depth and int(env.state["episode"][1]) == 0
+    # now play the clone at the first position its mask shows (all-ones when nothing fits: that placement fails and the
+    # next sequence of the stream starts): every item it is shown must be the source stream's
+    rng = random.Random(seed + base + 0)
+    seqs = [sequences.cut2_sequence(size, (2, 5), rng) for _ in range(8)]
+    a = np.full(E, NOOP, np.int64)
+    o = env.step(a)                                   # observe
+    episode, cursor = 0, 2
+    for k in range(45):
+        want = seqs[episode][cursor] if cursor < len(seqs[episode]) else tuple(size)
+        assert shown(o["obs"], 1) == tuple(want), (k, episode, cursor)
+        a[1] = int(np.flatnonzero(o["mask"][1])[0])
+        o = env.step(a)
+        episode, cursor = (episode + 1, 0) if o["done"][1] else (episode, cursor + 1)
+    assert episode >= 2 and int(env.state["episode"][1]) == episode
+
+
+@pytest.mark.gpu
+def test_gpu_streaming_clone_and_preview_follow_the_sources_stream():
+    """BppVecEnv.clone_into / preview in streaming mode on the HIP path (same scenario as the emulated test above, 64
+    sources cloned at once while they race ahead by more than the ring depth)."""
+    import torch
+    import bpp_amd
+    size, E, base, seed, depth = (10, 10, 10), 256, 900, 12, 8
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=1)
+    env = bpp_amd.BppVecEnv(E, size, stream=spec, env_id_base=base, env_id_total=base + E, mask_rule="space")
+    env.reset()
+    for t in range(2):
+        env.step_tensors(env.sample_feasible(seed=1, step=t))
+    src, dst = torch.arange(0, 64), torch.arange(128, 192)
+    env.clone_into(src, dst)
+    keep = env.state_numpy().copy()
+    fail = torch.full((E,), env.NOOP, dtype=torch.int64)
+    fail[src] = -1
+    for t in range(2 * depth + 3):                     # the sources burn through > depth episodes, refilled every step
+        r = env.step_tensors(fail)
+    assert bool(r.done[src].all()) and int(env.state_numpy()["episode"][:64].min()) == 2 * depth + 3
+    A = 100
+    for b in (0, 17, 63):
+        g = 128 + b
+        rng = random.Random(seed + base + b)           # the SOURCE's generator
+        seqs = [sequences.cut2_sequence(size, (2, 5), rng) for _ in range(6)]
+        episode, cursor = int(keep["episode"][b]), int(keep["cursor"][b])
+        assert episode == 0
+        pv = env.preview(4)[g].cpu().numpy()
+        want_pv = [(seqs[0] + [tuple(size)] * 4)[cursor + k] for k in range(4)]
+        assert [tuple(int(v) for v in row) for row in pv] == want_pv
+    r = env.observe()
+    a = torch.full((E,), env.NOOP, dtype=torch.int64)
+    track = {b: [0, int(keep["cursor"][b])] for b in (0, 17, 63)}
+    gens = {b: random.Random(seed + base + b) for b in track}
+    seqs = {b: [sequences.cut2_sequence(size, (2, 5), gens[b]) for _ in range(8)] for b in track}
+    for k in range(40):
+        obs, mask = r.obs.cpu().numpy(), r.mask.cpu().numpy()
+        for b, (ep, cur) in track.items():
+            g = 128 + b
+            want = seqs[b][ep][cur] if cur < len(seqs[b][ep]) else tuple(size)
+            assert tuple(int(obs[g, (p + 1) * A]) for p in range(3)) == tuple(want), (b, k)
+            a[g] = int(np.flatnonzero(mask[g])[0])
+        r = env.step_tensors(a)
+        done = r.done.cpu().numpy()
+        for b in track:
+            track[b] = [track[b][0] + 1, 0] if done[128 + b] else [track[b][0], track[b][1] + 1]
+    assert min(t[0] for t in track.values()) >= 1
+
+
+@pytest.mark.gpu
+def test_gpu_stream_checkpoints_are_validated_on_load():
+    """a streaming checkpoint only loads into a streaming env of the same geometry, depth, seed and shard."""
+    import bpp_amd
+    size = (10, 10, 10)
+    spec = dict(bound=(2, 5), seed=5, depth=6, refill_every=3)
+    env = bpp_amd.BppVecEnv(64, size, stream=spec)
+    env.reset()
+    sd = env.state_dict()
+    pool_env = bpp_amd.BppVecEnv(64, size, pool=bpp_amd.sequences.cut2_pool(size, 8, seed=0))
+    with pytest.raises(ValueError, match="streaming"):
+        pool_env.load_state_dict(sd)
+    with pytest.raises(ValueError, match="pool-based"):
+        env.load_state_dict(pool_env.state_dict())
+    for other in (dict(spec, seed=6), dict(spec, depth=8, refill_every=3), dict(spec, bound=(2, 4))):
+        with pytest.raises(ValueError, match="stream_spec"):
+            bpp_amd.BppVecEnv(64, size, stream=other).load_state_dict(sd)
+    with pytest.raises(ValueError, match="stream_spec"):
+        bpp_amd.BppVecEnv(64, size, stream=spec, env_id_base=64, env_id_total=128).load_state_dict(sd)
+    bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(sd)      # the matching env loads
