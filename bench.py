@@ -320,17 +320,23 @@ def main():
         torch.cuda.synchronize(device)
         return time.perf_counter() - t0
 
-    def repetitions(first, target_s):
-        reps = args.reps if args.reps > 0 else max(3, min(5000, int(target_s / max(first, 1e-6)) + 1))
-        if world > 1:   # every rank must run the same number of repetitions
-            rt = torch.tensor([reps], dtype=torch.int64, device=device)
+    def repeat_for(target_s, sets=None, log=True):
+        """Repetitions of the timed K-step region until their sum reaches `target_s` (three to begin with -- the first
+        one runs cold --, then as many as the fastest of those says are still needed; every rank runs the same number)."""
+        samples = [timed_region(sets, log) for _ in range(3)]
+        if args.reps > 0:
+            more = max(0, args.reps - 3)
+        else:
+            more = max(0, min(20000, int((target_s - sum(samples)) / max(min(samples), 1e-6)) + 1))
+        if world > 1:
+            rt = torch.tensor([more], dtype=torch.int64, device=device)
             dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-            reps = int(rt.item())
-        return reps
+            more = int(rt.item())
+        samples += [timed_region(sets, log) for _ in range(more)]
+        return all_max(samples)
 
-    first = timed_region()
-    reps = repetitions(first, 0.2)
-    samples = all_max([first] + [timed_region() for _ in range(reps - 1)])
+    samples = repeat_for(0.21)
+    reps = len(samples)
     dt = sorted(samples)[len(samples) // 2]
     stats.collect(env).all_reduce()   # whatever finished since the last logging point (outside the timed regions)
 
@@ -368,9 +374,8 @@ def main():
         R = max(3, int(1.07e9 / set_bytes) + 1)
         sets = env.output_sets(R)
         drive(2 * R, sets)
-        f0 = timed_region(sets, log=False)
-        reps_l3 = repetitions(f0, 0.1)
-        s_l3 = all_max([f0] + [timed_region(sets, log=False) for _ in range(reps_l3 - 1)])
+        s_l3 = repeat_for(0.1, sets, log=False)
+        reps_l3 = len(s_l3)
         dt_l3 = sorted(s_l3)[len(s_l3) // 2]
         kern_l3_ms = sorted(event_timed(n_ev, sets) for _ in range(3))[1]
         past = {"output_sets": R, "output_span_MB": round(R * set_bytes / 1e6, 1), "reps": reps_l3,

@@ -279,6 +279,12 @@ int bpp_gen_cut1(uint8_t *pool, int32_t *lengths, int32_t n, int32_t T, int32_t 
 int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_t H, const int32_t *box_set, int32_t n_box,
                uint64_t seed0, int32_t threads);
 
+/* VecEnv.step_wait()'s host side (acktr/envs.py:189-193 hands the loop a CPU reward tensor and a numpy `done`): copy
+ * `nbytes` from device memory to (page-locked) host memory behind everything enqueued on `stream` and wait for it --
+ * hipMemcpyAsync + hipStreamSynchronize in one call.  BppVecEnv.step() fetches reward + done (5 bytes per bin) with
+ * it.  The only entry point that blocks the calling thread. */
+int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, void *stream);
+
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }
  * on `stream` from one host call.  out->mask must hold the mask of the current observations (as left

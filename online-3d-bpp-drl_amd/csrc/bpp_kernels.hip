@@ -2275,6 +2275,14 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
     return rc;
 }
 
+int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, void *stream) {
+    if (!device_src || !host_dst || nbytes <= 0) return fail(BPP_E_BADARG, "bpp_fetch_to_host: NULL pointer / non-positive size");
+    hipError_t e = hipMemcpyAsync(host_dst, device_src, (size_t)nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
+    e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
+}
+
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream) {
     if (!b || !outs || !actions || nsets < 1) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: NULL pointer / no output set");

@@ -41,13 +41,16 @@ class StepTensors(object):
         return torch.ones((self.done.numel(), 1), dtype=torch.float32, device=self.done.device)
 
     def _to_host(self, nbytes):
-        """The first `nbytes` of the per-bin scalar block as a numpy byte array that the caller OWNS (copied out of the
-        page-locked staging buffer: those are reused round-robin)."""
-        if self._stage is not None:     # page-locked staging buffer of the env: a pageable destination runs at a fraction of the link's speed
-            pinned = self._stage()
-            pinned[:nbytes].copy_(self._small[:nbytes], non_blocking=True)
-            torch.cuda.current_stream(self._small.device).synchronize()
-            return pinned.numpy()[:nbytes].copy()
+        """The first `nbytes` of the per-bin scalar block as a numpy byte array in page-locked host memory (a pageable
+        destination runs at a fraction of the link's speed).  One native call: hipMemcpyAsync behind the step + stream
+        synchronise (bpp_fetch_to_host).  The array is a view of a staging buffer that the env hands out again only
+        once nobody holds a view of it any more, so whatever is built on it stays valid for as long as it is referenced."""
+        if self._stage is not None:
+            host = self._stage()
+            dev = self._small.device
+            _lib.check(_lib.lib().bpp_fetch_to_host(self._small.data_ptr(), host.ctypes.data, int(nbytes),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            return host[:nbytes]
         return self._small[:nbytes].cpu().numpy()
 
     def host_reward_done(self):
@@ -95,7 +98,7 @@ class LazyInfos(object):
         self._t = t_now
         self._done = None if done is None else np.asarray(done).astype(bool)
         self._serial = serial
-        self._fin = None       # {bin: (ep_ret, ep_len, ratio, counter)} of the finished bins
+        self._fin = None       # (bins, [ep_ret, ratio], [ep_len, counter]) of the finished bins
         self._live = None      # (counter, ratio) arrays of all bins
         self._dicts = None
 
@@ -123,7 +126,7 @@ class LazyInfos(object):
             else:       # plain arrays (host tests)
                 f64 = np.stack([r.ep_ret.cpu().numpy()[idx], r.ratio.cpu().numpy()[idx]])
                 i32 = np.stack([r.ep_len.cpu().numpy()[idx], r.counter.cpu().numpy()[idx]])
-            self._fin = {int(e): (float(f64[0, k]), int(i32[0, k]), np.float64(f64[1, k]), int(i32[1, k])) for k, e in enumerate(idx)}
+            self._fin = (idx, f64, i32)
         return self._fin
 
     def _running(self):
@@ -138,10 +141,11 @@ class LazyInfos(object):
 
     def _make(self, i):
         if self._done_mask()[i]:
-            ep_ret, ep_len, ratio, counter = self._finished()[i]
-            return {"counter": counter, "ratio": ratio,
+            idx, f64, i32 = self._finished()
+            k = int(np.searchsorted(idx, i))
+            return {"counter": int(i32[1, k]), "ratio": np.float64(f64[1, k]),
                     "mask": np.ones(shape=self._env.act_len),                  # bin3D.py:111
-                    "episode": {"r": round(ep_ret, 6), "l": ep_len,
+                    "episode": {"r": round(float(f64[0, k]), 6), "l": int(i32[0, k]),
                                 "t": round(self._t - self._env._tstart, 6)}}   # bench/monitor.py:64
         counter, ratio = self._running()
         return {"counter": int(counter[i]), "ratio": np.float64(ratio[i])}
@@ -324,16 +328,23 @@ class BppVecEnv(object):
         return b, out
 
     def _staging(self):
-        """Next of four page-locked host buffers for the per-bin scalars of a step (a device->host copy into pageable
-        memory runs at a fraction of the link's speed).  Callers copy what they keep out of it (StepTensors._to_host)."""
-        ring = getattr(self, "_stage_ring", None)
+        """A page-locked host buffer (numpy uint8 view) for the per-bin scalars of a step that nobody else references:
+        buffers handed out earlier come back into use only when every view of them (the CPU reward tensor, `done`) has
+        been dropped -- checked by reference count --, otherwise a new one is pinned.  The reference loop copies reward
+        and done into its rollout storage at once, so two or three buffers circulate."""
+        import sys
+        pool = getattr(self, "_stage_pool", None)
         n = self._bufs["_small"].numel() if self._bufs is not None else 0
-        if ring is None or ring[0].numel() != n:
-            ring = self._stage_ring = [torch.empty((n,), dtype=torch.uint8).pin_memory() for _ in range(4)]
-            self._stage_next = 0
-        buf = ring[self._stage_next]
-        self._stage_next = (self._stage_next + 1) % len(ring)
-        return buf
+        if pool is None or (pool and pool[0][1].size != n):
+            pool = self._stage_pool = []
+        for k, (t, a) in enumerate(pool):
+            if sys.getrefcount(a) <= 3:          # the pool's tuple, the loop variable, getrefcount's argument
+                pool.append(pool.pop(k))
+                return a
+        t = torch.empty((n,), dtype=torch.uint8).pin_memory()
+        a = t.numpy()
+        pool.append((t, a))
+        return a
 
     def _buffers(self):
         if self.fresh_outputs or self._bufs is None:
@@ -479,7 +490,7 @@ class BppVecEnv(object):
         if r is None:
             raise RuntimeError("step_wait() without step_async()")
         rew, done = r.host_reward_done()            # ONE device->host copy: 5 bytes per bin
-        done = done.astype(bool)
+        done = done.view(np.bool_)                  # the kernels write exactly 0 / 1
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
 

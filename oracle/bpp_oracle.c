@@ -460,6 +460,13 @@ int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear
     return 0;
 }
 
+int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, void *stream) {
+    (void)stream;
+    if (!device_src || !host_dst || nbytes <= 0) return fail(BPP_E_BADARG, "bpp_fetch_to_host: NULL pointer / non-positive size");
+    memmove(host_dst, device_src, (size_t)nbytes);      /* host pointers on both sides here */
+    return 0;
+}
+
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream) {
     if (!b || !outs || !actions || nsets < 1) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: NULL pointer / no output set");
