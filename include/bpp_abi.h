@@ -65,7 +65,8 @@ typedef struct bpp_env_state {
     uint32_t item_cur;   /* pool[seq][min(cursor, T-1)]: BoxCreator.preview(1)[0], binCreator.py:15-18  */
     uint32_t item_next;  /* pool[seq][min(cursor+1, T-1)]: the item shown after a successful placement  */
     uint32_t item_reset; /* pool[next episode's row][0]: the item shown after a failed placement        */
-    uint32_t pad;
+    uint32_t hmax;       /* height of the bin's highest cell, max(space.plain): lets the 20x20 kernel pick the
+                            one-word histogram for bins that are still low (csrc/bpp_tile_kernel.inl: kLowTop)   */
 } bpp_env_state;
 
 /* One shard of bins living on one device.  Replaces N x (PackingGame + Space + BoxCreator +

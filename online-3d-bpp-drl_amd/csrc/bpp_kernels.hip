@@ -361,6 +361,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 st.cursor += 1;  // bin3D.py:116-117
                 st.item_cur = it_nxt;
                 st.item_next = sp_ok;
+                st.hmax = max(st.hmax, (uint32_t)top);   // highest cell of the bin
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 st.item_cur = it_rst;
                 st.item_next = sp_f1;
                 st.item_reset = sp_f2;
+                st.hmax = 0;
                 r.item = it_rst;
                 r.flags = 2u;
             }
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.item_cur = p.pool[(size_t)st.seq * p.T];
             st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
             st.item_reset = p.pool[(size_t)sn * p.T];
-            st.pad = 0;
+            st.hmax = 0;
             p.state[e] = st;
             r.item = st.item_cur;
             r.flags = 2u;
@@ -588,8 +590,12 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
     }
     mh = -1;
     ma = 0;
+    // (rare path -- items wider than 5 x 6, in the benchmark only the bin-sized terminator: kept rolled, an unrolled
+    // copy of these loops was what set the kernels' scalar-register count and cost the 10x10 + rotation kernel a workgroup slot per CU)
+#pragma unroll 1
     for (int a0 = 0; a0 < x; a0 += kTileX) {
         const int xa = min(kTileX, x - a0);
+#pragma unroll 1
         for (int b0 = 0; b0 < y; b0 += kTileY) {
             const int yb = min(kTileY, y - b0);
             int m, c;
@@ -897,6 +903,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 st.cursor += 1;                                        // bin3D.py:116-117
                 st.item_cur = it_nxt;
                 st.item_next = sp_ok;
+                st.hmax = max(st.hmax, (uint32_t)top);                 // highest cell of the bin
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
                 r.flags = 1u | ((uint32_t)top << 8);
@@ -913,6 +920,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 st.item_cur = it_rst;
                 st.item_next = sp_f1;
                 st.item_reset = sp_f2;
+                st.hmax = 0;
                 r.item = it_rst;
                 r.flags = 2u;
             }
@@ -938,7 +946,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             st.item_cur = p.pool[(size_t)st.seq * p.T];
             st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
             st.item_reset = p.pool[(size_t)sn * p.T];
-            st.pad = 0;
+            st.hmax = 0;
             if (active) p.state[e] = st;
             r.item = st.item_cur;
             r.flags = 2u;
@@ -2029,8 +2037,8 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
     if (l.tile >= 0) {   // step kernel shape (TileGeo<...>::LDS_BLOCK restated for runtime arguments)
         const TileGeoEntry &g = kTileGeo[l.tile];
         const int A = W * L, M = A * (1 + rotation), npass = (A + kWave - 1) / kWave, nbw = g.epw * l.nit;
-        const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M), off_slot = off_rec + nbw * (int)sizeof(BinRec);
-        const int off_bal = off_slot + (g.epw > 1 ? g.epw * 2 * (int)sizeof(SlotRec) : 0);
+        const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M);
+        const int off_bal = (off_rec + nbw * (int)sizeof(TileRec) + 7) & ~7;
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
         lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K);
         out[2] = nbw;

@@ -35,22 +35,30 @@ __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 
-// Constants of one (bin, orientation) of the item on display, computed lane-parallel for all the wave's bins at once
-// (one lane per slot) and read back wave-uniformly by the candidate loop: two LDS reads and eight readfirstlane per
-// slot instead of ~100 scalar instructions per bin.
-struct __attribute__((aligned(16))) SlotRec {
-    uint32_t w[8];
-    // w0: index-decode multiplier ceil(2^22 / nj) (23 bits) | nj << 24
-    // w1: nv (candidates, 11 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
-    // w2: x * PW entries (prefix-image row offset) | y << 16
-    // w3: (x - 1) * L (corner offset) | (y - 1) << 16
-    // w4: t95 | t85 << 16          w5: t50 | x << 16 | y << 24
-    // w6: hash32(seed, global bin id, step) of the fused draw      w7: unused
+// Constants of one (bin, orientation) of the item on display: computed lane-parallel for all the wave's bins at once
+// (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
+// candidate loop with v_readlane -- no LDS round trip, ~100 scalar instructions per bin saved.
+//   w0: index-decode multiplier ceil(2^22 / nj) (23 bits) | nj << 24
+//   w1: nv (candidates, 11 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
+//   w2: x * PW entries (prefix-image row offset) | y << 16
+//   w3: (x - 1) * L (corner offset) | (y - 1) << 16
+//   w4: t95 | t85 << 16          w5: t50 | x << 16 | y << 24
+//   w6: hash32(seed, global bin id, step) of the fused draw
+// Per-bin record in LDS written by the deciding wave (or, in the mask-only modes, by the owning wave), read by the
+// bin's lanes: 12 bytes.
+struct TileRec {
+    uint32_t item;   // item shown in the next observation: x | y<<8 | z<<16
+    uint32_t place;  // lx | ly<<8 | x<<16 | y<<24 of the box just placed
+    uint32_t flags;  // bit0 placed, bit1 reset (zero the map), bit2 every height of the bin <= kLowTop, bits 8.. new top height
 };
+// A bin none of whose heights exceeds 11 fits ONE 64-bit histogram word (12 levels of 5 bits): the 20x20x20 kernel
+// (K = 2) then builds and scans a K = 1 prefix image for it -- 83 % of the (bin, lock-step) pairs under the
+// benchmark's policy (episodes end long before the pallet is half full), half the prefix-image work and LDS traffic.
+constexpr int kLowTop = kLevelsPerWord - 1;
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
-// The six words of a SlotRec that the candidate loop consumes, from the item on display (same code for the
+// The six words of a slot that the candidate loop consumes, from the item on display (same code for the
 // lane-parallel and the scalar-unit evaluation).
 template <int W, int L>
 __device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[6]) {
@@ -83,10 +91,9 @@ struct TileGeo {
     static constexpr int NPASS = (A + kWave - 1) / kWave;  // candidate passes per orientation (at most A candidates)
     static constexpr int OFF_MK = round16(NBW * A);                              // after the NBW byte tiles
     static constexpr int OFF_REC = round16(OFF_MK + EPW * M);                    // mask bytes of the current group
-    static constexpr int OFF_SLOT = OFF_REC + NBW * (int)sizeof(BinRec);         // per (bin, orientation) constants
     // (LDS is handed out in 1280-byte granules on gfx950: the 20x20, K = 2 workgroup must stay <= 32 000 bytes for five
-    // workgroups per CU -- the slot records are therefore only used, and only allocated, when a wave owns several bins)
-    static constexpr int OFF_BAL = OFF_SLOT + (EPW > 1 ? EPW * 2 * (int)sizeof(SlotRec) : 0);   // ballots of the candidate passes
+    // workgroups per CU, the 10x10 + rotation one <= 20 480 for eight -- it is exactly 20 480)
+    static constexpr int OFF_BAL = (OFF_REC + NBW * (int)sizeof(TileRec) + 7) & ~7;   // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
     static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;                    // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
@@ -112,8 +119,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     uint8_t *hmw = wb;                                 // [NBW][A] byte tiles of all the wave's bins
     uint8_t *mk = wb + T::OFF_MK;
     uint32_t *mk32 = (uint32_t *)mk;
-    BinRec *recw = (BinRec *)(wb + T::OFF_REC);        // [NBW]
-    SlotRec *slots = (SlotRec *)(wb + T::OFF_SLOT);    // [EPW][2]
+    TileRec *recw = (TileRec *)(wb + T::OFF_REC);      // [NBW]
     uint64_t *balm = (uint64_t *)(wb + T::OFF_BAL);
     Ent<K> *P = (Ent<K> *)(wb + T::OFF_P);
     const uint32_t hclamp = (uint32_t)p.H + 1u;        // heights above H all behave like H+1 (never feasible)
@@ -183,8 +189,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             }
         }
     }
+    // The mask-only entry points have no per-bin chain: every wave fetches its own bins' items and nothing crosses
+    // waves -- no workgroup barrier at all (round 2 ran them through the deciding wave and both barriers).
+    constexpr bool kDecide = MODE == kStep || MODE == kResetInit || MODE == kResetAdvance;
     BPP_STAMP(p, 1);
-    __syncthreads();  // wave 0 reads the other waves' tiles below
+    if constexpr (kDecide) __syncthreads();  // wave 0 reads the other waves' tiles below
+    else wave_sync();
     BPP_STAMP(p, 2);
 
     // ---- phase 2: per-bin scalar chain in wave 0, LPB lanes per bin -------------------------------------
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     float out_rew = 0.0f;
     int fin_len = 0, out_boxes = 0;
     bpp_env_state st_out;
-    if (wid == 0 && !BPP_ABL(p, 32)) {
+    if (kDecide && wid == 0 && !BPP_ABL(p, 32)) {
         __builtin_amdgcn_s_setprio(3);                 // the other waves of the workgroup wait for this chain
         const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
         dlead = lead;
@@ -201,11 +211,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         const int ow = db / NBW, oel = db % NBW;       // owning wave, bin within it
         unsigned char *ob = smem + ow * T::LDS_WAVE;
         const uint8_t *ohm = ob + oel * A;
-        BinRec r;
+        TileRec r;
         r.item = 0;
         r.place = 0;
         r.flags = 0;
-        r.any = 0;
         if (MODE == kStep) {
             bpp_env_state st = st0;
             const int64_t act = act0;
@@ -300,11 +309,13 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 st.cursor += 1;                                        // bin3D.py:116-117
                 st.item_cur = it_nxt;
                 st.item_next = sp_ok;
+                st.hmax = max(st.hmax, (uint32_t)top);                 // highest cell of the bin (space.py:42-45 raised the window to `top`)
                 r.item = it_nxt;
                 r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
-                r.flags = 1u | ((uint32_t)top << 8);
+                r.flags = 1u | ((uint32_t)top << 8) | (st.hmax <= (uint32_t)kLowTop ? 4u : 0u);
             } else if (noop) {
                 r.item = it_cur;
+                r.flags = st.hmax <= (uint32_t)kLowTop ? 4u : 0u;
             } else {                                                   // shmem_vec_env.py:128-129
                 st.episode += 1;
                 st.seq = seq_n;
@@ -316,8 +327,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 st.item_cur = it_rst;
                 st.item_next = sp_f1;
                 st.item_reset = sp_f2;
+                st.hmax = 0;
                 r.item = it_rst;
-                r.flags = 2u;
+                r.flags = 2u | 4u;
             }
             st_out = st;   // written behind the second barrier (it waits for the speculative pool loads)
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
@@ -341,19 +353,29 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             st.item_cur = p.pool[(size_t)st.seq * p.T];
             st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
             st.item_reset = p.pool[(size_t)sn * p.T];
-            st.pad = 0;
+            st.hmax = 0;
             if (lead) p.state[e] = st;
             r.item = st.item_cur;
-            r.flags = 2u;
-        } else if (MODE == kMaskObs) {
-            const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
-            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
-        } else {
-            const int32_t *it = p.items_in + (size_t)e * 3;
-            r.item = pack_item(it[0], it[1], it[2]);
+            r.flags = 2u | 4u;
         }
-        if (lead) ((BinRec *)(ob + T::OFF_REC))[oel] = r;
+        if (lead) ((TileRec *)(ob + T::OFF_REC))[oel] = r;
         __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (!kDecide) {   // mask-only entry points: the owning wave reads its bins' items itself (NIT == 1)
+        if (el < wnenv && sl == 0) {
+            const int e = we0 + el;
+            TileRec r;
+            if (MODE == kMaskObs) {
+                const float *o = p.obs_in + (size_t)e * 4 * A;         // acktr/utils.py:43-45
+                r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
+            } else {
+                const int32_t *it = p.items_in + (size_t)e * 3;
+                r.item = pack_item(it[0], it[1], it[2]);
+            }
+            r.place = 0;
+            r.flags = 0;
+            recw[el] = r;
+        }
     }
     // work that does not depend on the decisions, done by the waiting waves while wave 0 decides: clear the first
     // group's mask bytes and the zero row / column of the prefix image (never written again)
@@ -372,7 +394,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
     }
     BPP_STAMP(p, 3);
-    __syncthreads();
+    if constexpr (kDecide) __syncthreads();
+    else wave_sync();
     BPP_STAMP(p, 4);
     if (MODE == kStep && wid == 0 && dlead) {   // per-bin outputs and the state record, off the other waves' path
         const int e = dec_e;
@@ -409,24 +432,23 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         const bool mine = el < nenv;
         uint8_t *hm = hmw + it * EPW * A;
         uint32_t *hm32 = (uint32_t *)hm;
-        BinRec *rec = recw + it * EPW;
+        TileRec *rec = recw + it * EPW;
         if (it > 0) wave_sync();   // the previous group's mask bytes / prefix image have been consumed
         if (it == 0) BPP_STAMP(p, 5);
 
-        BinRec myrec;   // this lane's bin
+        TileRec myrec;   // this lane's bin
         myrec.item = 0;
         myrec.place = 0;
         myrec.flags = 0;
-        myrec.any = 0;
         if (mine) myrec = rec[el];
         const bool draw = MODE == kStep && p.next_action != nullptr;
-        // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once
-        SlotRec slot;
-        constexpr bool kResets = MODE == kStep || MODE == kResetInit || MODE == kResetAdvance;   // a bin that was just reset
+        // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once;
+        // they stay in this lane's registers and are read with v_readlane by the candidate loop
+        uint32_t slotw[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        constexpr bool kResets = kDecide;                      // a bin that was just reset
         if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) {           // shows an empty map: its mask is the in-range rectangle
-            make_slot_words<W, L>(myrec.item, sl, kResets && (myrec.flags & 2u) != 0u, ROT, p.H, slot.w);
-            slot.w[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
-            slot.w[7] = 0u;
+            make_slot_words<W, L>(myrec.item, sl, kResets && (myrec.flags & 2u) != 0u, ROT, p.H, slotw);
+            slotw[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
         }
 
         if (MODE == kStep) {
@@ -480,44 +502,65 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
 
         if (it == 0) BPP_STAMP(p, 7);
+        // Histogram words of this group's prefix image: K, or ONE word for a 20x20 bin whose heights all fit it (kLowTop).
+        // Wave-uniform: such a wave owns a single bin.
+        bool low = false;
+        if constexpr (K == 2 && EPW == 1) {
+            if constexpr (kDecide) {
+                low = ((uint32_t)__builtin_amdgcn_readfirstlane(rec[0].flags) & 4u) != 0u;   // from the state record's hmax
+            } else {                                           // mask-only: the caller's heights, whatever they are
+                uint32_t mx = 0;
+#pragma unroll
+                for (int k = 0; k < KQ; ++k)
+                    if (sl + G * k < A4) {
+                        const uint32_t v = hm32[sl + G * k];
+                        mx = max(max(mx, v & 255u), max(max((v >> 8) & 255u, (v >> 16) & 255u), v >> 24));
+                    }
+                low = __ballot(mx > (uint32_t)kLowTop) == 0ull;
+            }
+        }
+        uint32_t anymask = 0;                                  // bit b: bin b of the group has a feasible position
+        auto phase4 = [&](auto kk_c) {
+        constexpr int KK = decltype(kk_c)::value;
+        Ent<KK> *P = (Ent<KK> *)(wb + T::OFF_P);               // (shadows the kernel's K-word view of the same bytes)
         // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
         if (!BPP_ABL(p, 1)) {
             if constexpr (EPW == 1) {
-                if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
+                if (nenv > 0) build_prefix_one_bin<W, L, KK>(hm, P, hclamp, lane);
             } else {
-                Ent<K> zero;   // (row 0 and column 0 of every image were cleared before the second barrier)
+                Ent<KK> zero;   // (row 0 and column 0 of every image were cleared before the second barrier)
 #pragma unroll
-                for (int k = 0; k < K; ++k) zero.w[k] = 0;
+                for (int k = 0; k < KK; ++k) zero.w[k] = 0;
                 for (int t = lane; t < nenv * W; t += kWave) {                 // running sums along each row
                     const int b = t / W, i = t - b * W;
                     const uint8_t *row = hm + b * A + i * L;
-                    Ent<K> *pr = P + b * PN + (i + 1) * PW + 1;
-                    Ent<K> s = zero;
+                    Ent<KK> *pr = P + b * PN + (i + 1) * PW + 1;
+                    Ent<KK> s = zero;
                     uint32_t hv[L];
     #pragma unroll
                     for (int j = 0; j < L; ++j) hv[j] = row[j];
     #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        const Ent<K> c = code_of<K>(min(hv[j], hclamp));
+                        const Ent<KK> c = code_of<KK>(min(hv[j], hclamp));
     #pragma unroll
-                        for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
+                        for (int k = 0; k < KK; ++k) s.w[k] += c.w[k];
                         pr[j] = s;
                     }
                 }
                 wave_sync();
                 for (int t = lane; t < nenv * L; t += kWave) {                 // then down each column
                     const int b = t / L, j = t - b * L;
-                    Ent<K> *pc = P + b * PN + PW + (j + 1);
-                    Ent<K> s = zero;
+                    Ent<KK> *pc = P + b * PN + PW + (j + 1);
+                    Ent<KK> s = zero;
                     constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
                     for (int i0 = 0; i0 < W; i0 += CH) {
-                        Ent<K> v[CH];
+                        Ent<KK> v[CH];
     #pragma unroll
                         for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
     #pragma unroll
                         for (int i = 0; i < CH; ++i) {
     #pragma unroll
-                            for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
+                            for (int k = 0; k < KK; ++k) s.w[k] += v[i].w[k];
                             pc[(i0 + i) * PW] = s;
                         }
                     }
@@ -534,10 +577,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
         }
         wave_sync();
-        if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) slots[el * 2 + sl] = slot;   // computed right after the bin records were read
-        wave_sync();
         for (int b = 0; b < (BPP_ABL(p, 2) ? 0 : nenv); ++b) {
-            const Ent<K> *Pe = P + b * PN;
+            const Ent<KK> *Pe = P + b * PN;
             const uint8_t *he = hm + b * A;
             uint8_t *me = mk + b * M;
             uint64_t balr[2][BAL_REGS ? NPASS : 1];   // ballots of the passes (scalar registers after unrolling)
@@ -546,15 +587,14 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             int tot = 0;                              // feasible candidates so far (both orientations)
 #pragma unroll
             for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
-                // the slot's constants, wave-uniform: two LDS reads, then scalar registers -- or, when the wave owns a
-                // single bin, straight from the item on the scalar unit
+                // the slot's constants, wave-uniform: read from the registers of the slot's lane -- or, when the wave
+                // owns a single bin, straight from the item on the scalar unit
                 uint32_t w0, w1, w2, w3, w4, w5;
                 if constexpr (EPW > 1) {
-                    const uint4 qa = *(const uint4 *)&slots[b * 2 + rot].w[0], qb = *(const uint4 *)&slots[b * 2 + rot].w[4];
-                    w0 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.y);
-                    w2 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane(qa.w);
-                    w4 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.x), w5 = (uint32_t)__builtin_amdgcn_readfirstlane(qb.y);
-                    if (rot == 0) hsh = (uint32_t)__builtin_amdgcn_readfirstlane(qb.z);
+                    const int src = b * G + rot;           // lane (el = b, sl = rot)
+                    w0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], src), w1 = (uint32_t)__builtin_amdgcn_readlane(slotw[1], src);
+                    w2 = (uint32_t)__builtin_amdgcn_readlane(slotw[2], src), w3 = (uint32_t)__builtin_amdgcn_readlane(slotw[3], src);
+                    w4 = (uint32_t)__builtin_amdgcn_readlane(slotw[4], src), w5 = (uint32_t)__builtin_amdgcn_readlane(slotw[5], src);
                 } else {
                     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].item);
                     const uint32_t flg = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].flags);
@@ -569,8 +609,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 const int xPW = (int)(w2 & 0xffffu), y = (int)(w2 >> 16), x = (int)((w5 >> 16) & 255u);
                 const int o10 = (int)(w3 & 0xffffu), o01 = (int)(w3 >> 16);
                 const int t95 = (int)(w4 & 0xffffu), t85 = (int)(w4 >> 16), t50 = (int)(w5 & 0xffffu);
-                dec_od[rot] = od;
-                dec_nj[rot] = (uint32_t)nj;
+                if constexpr (EPW == 1) {
+                    dec_od[rot] = od;
+                    dec_nj[rot] = (uint32_t)nj;
+                }
 #pragma unroll
                 for (int ps = 0; ps < (BAL_REGS ? NPASS : 1); ++ps) balr[rot][ps] = 0ull;
                 if (!BAL_REGS) {
@@ -606,16 +648,16 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                             if (EMPTY) {
                                 f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
                             } else {
-                                const Ent<K> *Pb = Pe + i * PW + j;
+                                const Ent<KK> *Pb = Pe + i * PW + j;
                                 int mh, ma;
                                 if (!BIG) {
-                                    const Ent<K> a = Pb[0], bb = Pb[y], cc = Pb[xPW], d = Pb[xPW + y];
-                                    Ent<K> h;
+                                    const Ent<KK> a = Pb[0], bb = Pb[y], cc = Pb[xPW], d = Pb[xPW + y];
+                                    Ent<KK> h;
     #pragma unroll
-                                    for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
-                                    top_of<K>(h, mh, ma);
+                                    for (int k = 0; k < KK; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
+                                    top_of<KK>(h, mh, ma);
                                 } else {
-                                    window_top<K>(Pe, PW, i, j, x, y, mh, ma);
+                                    window_top<KK>(Pe, PW, i, j, x, y, mh, ma);
                                 }
                                 const uint8_t *hb = he + i * L + j;
                                 const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
@@ -648,7 +690,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     run(FF{}, FF{});
                 wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
             }
-            if (lane == 0) rec[b].any = tot > 0 ? 1u : 0u;
+            anymask |= tot > 0 ? 1u << b : 0u;
 
             // ---- phase 4c (optional): draw the next action uniformly among the feasible entries -------------
             // Same result as bpp_sample_feasible on the mask this step writes: pick = hash * count >> 32, the
@@ -656,11 +698,15 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
             if (draw) {
                 const int e = e0 + b;
+                if constexpr (EPW > 1) hsh = (uint32_t)__builtin_amdgcn_readlane(slotw[6], b * G);
                 if (tot == 0) {
                     if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
                 } else {
+                    // the winning pass, on the scalar unit: the first (orientation, pass) whose running count exceeds `rem`
                     int rem = (int)__umulhi(hsh, (uint32_t)tot);
                     bool found = false;
+                    unsigned long long wbl = 0ull;
+                    int wrot = 0, wps = 0;
     #pragma unroll
                     for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {
     #pragma unroll(BAL_REGS ? NPASS : 1)
@@ -676,28 +722,41 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                 bl = ((unsigned long long)vhi << 32) | (unsigned long long)vlo;
                             }
                             const int c = __popcll(bl);
-                            if (!found && rem < c) {
-                                found = true;
-                                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
-                                if (((bl >> lane) & 1ull) && (int)below == rem) {
-                                    const int t = lane + ps * kWave;
-                                    const int i = (int)(((uint32_t)t * dec_od[rot]) >> kCandShift), j = t - i * (int)dec_nj[rot];
-                                    p.next_action[e] = (int64_t)(rot * A + i * L + j);
-                                }
-                            }
+                            const bool hit = !found && rem < c;
+                            wbl = hit ? bl : wbl;
+                            wrot = hit ? rot : wrot;
+                            wps = hit ? ps : wps;
+                            found = found || hit;
                             rem -= found ? 0 : c;
                         }
+                    }
+                    // index decode of the winning orientation (the slot's first word again)
+                    uint32_t od, nj;
+                    if constexpr (EPW > 1) {
+                        const uint32_t ww0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], b * G + wrot);
+                        od = ww0 & 0xffffffu, nj = ww0 >> 24;
+                    } else {
+                        od = wrot ? dec_od[ROT ? 1 : 0] : dec_od[0], nj = wrot ? dec_nj[ROT ? 1 : 0] : dec_nj[0];
+                    }
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(wbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wbl, 0u));
+                    if (((wbl >> lane) & 1ull) && (int)below == rem) {
+                        const int t = lane + wps * kWave;
+                        const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * (int)nj;
+                        p.next_action[e] = (int64_t)(wrot * A + i * L + j);
                     }
                 }
             }
         }
         wave_sync();
+        };   // phase4
+        if (low) phase4(std::integral_constant<int, 1>{});
+        else phase4(std::integral_constant<int, K>{});
 
         if (it == 0) BPP_STAMP(p, 9);
         // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
         if (mine && !BPP_ABL(p, 4)) {
             float4 *gm = (float4 *)(p.mask + (size_t)(e0 + el) * M) + sl;
-            const bool anyf = rec[el].any != 0u;
+            const bool anyf = ((anymask >> el) & 1u) != 0u;
     #pragma unroll
             for (int k = 0; k < KM; ++k)
                 if (sl + G * k < M4) {

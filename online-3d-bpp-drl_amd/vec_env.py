@@ -660,5 +660,5 @@ class BppVecEnv(object):
         """bpp_env_state[E] as a structured numpy array (tests)."""
         dt = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),
                        ("ep_ret", "<f8"), ("ep_len", "<i4"), ("seq", "<i4"), ("item_cur", "<u4"), ("item_next", "<u4"),
-                       ("item_reset", "<u4"), ("pad", "<u4")])
+                       ("item_reset", "<u4"), ("hmax", "<u4")])
         return self.state.cpu().numpy().view(dt).reshape(-1)

@@ -192,7 +192,6 @@ static void refresh_item_cache(const bpp_batch *b, int e, bpp_env_state *s) {
     s->item_cur = pool_entry(b, s->seq, s->cursor);
     s->item_next = pool_entry(b, s->seq, s->cursor + 1);
     s->item_reset = pool_entry(b, seq_n, 0);
-    s->pad = 0;
 }
 
 /* PackingGame.cur_observation (envs/bpp0/bin3D.py:61-66) as float32 (shmem_vec_env.py:42-43) + mask. */
@@ -221,6 +220,7 @@ static void reset_bin(const bpp_batch *b, int e, bpp_env_state *s, int first) {
     s->vol_sum = 0;
     s->ep_ret = 0.0;
     s->ep_len = 0;
+    s->hmax = 0;
     s->seq = (int32_t)(first ? pool_row(b, e, 0) : next_row(b, s->seq));
 }
 
@@ -301,6 +301,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
                 for (int j = ly; j < ly + y; ++j) bytes[i * L + j] = (uint8_t)max_h;
             s->n_boxes += 1;
             s->vol_sum += x * y * z;
+            if ((uint32_t)max_h > s->hmax) s->hmax = (uint32_t)max_h;   /* include/bpp_abi.h: highest cell of the bin */
             /* bin3D.py:44-46,114,121: float64 (vol / binvol) * 10 */
             reward = ((double)(item[0] * item[1] * item[2]) / binvol) * 10.0;
             s->cursor += 1;                             /* bin3D.py:116-117 drop_box + generate_box_size */

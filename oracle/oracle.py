@@ -18,7 +18,7 @@ RESET_INIT, RESET_ADVANCE = 0, 1
 
 STATE_DTYPE = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),
                         ("ep_ret", "<f8"), ("ep_len", "<i4"), ("seq", "<i4"), ("item_cur", "<u4"), ("item_next", "<u4"),
-                        ("item_reset", "<u4"), ("pad", "<u4")])
+                        ("item_reset", "<u4"), ("hmax", "<u4")])
 assert STATE_DTYPE.itemsize == 48
 
 
