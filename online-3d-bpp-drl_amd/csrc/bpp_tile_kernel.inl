@@ -446,6 +446,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         // they stay in this lane's registers and are read with v_readlane by the candidate loop
         uint32_t slotw[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
         constexpr bool kResets = kDecide;                      // a bin that was just reset
+        constexpr bool kResetsOnly = MODE == kResetInit || MODE == kResetAdvance;   // every bin shows an empty map
         if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) {           // shows an empty map: its mask is the in-range rectangle
             make_slot_words<W, L>(myrec.item, sl, kResets && (myrec.flags & 2u) != 0u, ROT, p.H, slotw);
             slotw[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
@@ -635,23 +636,35 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     continue;
                 }
                 if (!valid) continue;                                       // item does not fit at all
-                // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
-                auto run = [&](auto big_c, auto empty_c) {
+                // One candidate loop per case, so that no bin-uniform condition is re-tested per candidate.  XC, YC != 0:
+                // the loop compiled for ONE item footprint -- every offset of the four prefix-image reads and the four
+                // corner reads is then an immediate, the thresholds and the index decode are literals, and a second pass
+                // exists only where (W - x + 1)(L - y + 1) > 64.  The sixteen footprints 2..5 x 2..5 are what CUT-2 / RS
+                // sequences consist of (acktr/arguments.py:122-128); anything else runs the XC = 0 form.
+                auto run = [&](auto big_c, auto empty_c, auto xc_c, auto yc_c) {
                     constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
+                    constexpr int XC = decltype(xc_c)::value, YC = decltype(yc_c)::value;
+                    constexpr bool SP = XC != 0;
+                    constexpr int cNJ = SP ? L - YC + 1 : 1, cNV = SP ? (W - XC + 1) * cNJ : 0, cAREA = XC * YC;
+                    constexpr uint32_t cOD = ((1u << kCandShift) + (uint32_t)cNJ - 1u) / (uint32_t)cNJ;
+                    const int c_nv = SP ? cNV : nv, c_nj = SP ? cNJ : nj, c_y = SP ? YC : y, c_xPW = SP ? XC * PW : xPW;
+                    const uint32_t c_od = SP ? cOD : od;
+                    const int c_o10 = SP ? (XC - 1) * L : o10, c_o01 = SP ? YC - 1 : o01;
+                    const int c_t95 = SP ? 19 * cAREA / 20 + 1 : t95, c_t85 = SP ? 17 * cAREA / 20 + 1 : t85, c_t50 = SP ? cAREA / 2 + 1 : t50;
     #pragma unroll(BAL_REGS ? NPASS : 1)
                     for (int ps = 0; ps < NPASS; ++ps) {
-                        if (ps * kWave >= nv) break;                        // wave-uniform
+                        if (ps * kWave >= c_nv) break;                      // wave-uniform (compile-time when SP)
                         const int t = lane + ps * kWave;
                         bool f = false;
-                        if (t < nv) {
-                            const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
+                        if (t < c_nv) {
+                            const int i = (int)(((uint32_t)t * c_od) >> kCandShift), j = t - i * c_nj;
                             if (EMPTY) {
                                 f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
                             } else {
                                 const Ent<KK> *Pb = Pe + i * PW + j;
                                 int mh, ma;
                                 if (!BIG) {
-                                    const Ent<KK> a = Pb[0], bb = Pb[y], cc = Pb[xPW], d = Pb[xPW + y];
+                                    const Ent<KK> a = Pb[0], bb = Pb[c_y], cc = Pb[c_xPW], d = Pb[c_xPW + c_y];
                                     Ent<KK> h;
     #pragma unroll
                                     for (int k = 0; k < KK; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
@@ -660,12 +673,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                     window_top<KK>(Pe, PW, i, j, x, y, mh, ma);
                                 }
                                 const uint8_t *hb = he + i * L + j;
-                                const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
+                                const int r00 = hb[0], r10 = hb[c_o10], r01 = hb[c_o01], r11 = hb[c_o10 + c_o01];
                                 // utils.py:23-33 on lane masks: all four corners at max_h -> t50, exactly three -> t85
                                 const bool e0c = r00 == mh, e1c = r10 == mh, e2c = r01 == mh, e3c = r11 == mh;
                                 const bool a01 = e0c && e1c, o01c = e0c || e1c, a23 = e2c && e3c, o23 = e2c || e3c;
                                 const bool all4 = a01 && a23, ge3 = (a01 && o23) || (a23 && o01c);
-                                const int thr = all4 ? t50 : (ge3 ? t85 : t95);
+                                const int thr = all4 ? c_t50 : (ge3 ? c_t85 : c_t95);
                                 f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
                                 if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
                                     const int rm = max(max(r00, r10), max(r01, r11));
@@ -682,12 +695,26 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 };
                 using TT = std::true_type;
                 using FF = std::false_type;
-                if (fresh)
-                    run(FF{}, TT{});
-                else if (big)
-                    run(TT{}, FF{});
-                else
-                    run(FF{}, FF{});
+                using I0 = std::integral_constant<int, 0>;
+                // footprint-specialised loops: the BASELINE geometries' step and mask kernels (resets only see empty maps)
+                constexpr bool kSpec = ((W == 10 && L == 10 && K == 1) || (W == 20 && L == 20 && K == 2)) && !kResetsOnly;
+                if (fresh) {
+                    run(FF{}, TT{}, I0{}, I0{});
+                } else if (big) {
+                    run(TT{}, FF{}, I0{}, I0{});
+                } else if (kSpec && (uint32_t)(x - 2) < 4u && (uint32_t)(y - 2) < 4u) {
+    #define BPP_FOOT(X, Y) case (X) * 8 + (Y): run(FF{}, FF{}, std::integral_constant<int, kSpec ? (X) : 0>{}, std::integral_constant<int, kSpec ? (Y) : 0>{}); break;
+                    switch (x * 8 + y) {
+                        BPP_FOOT(2, 2) BPP_FOOT(2, 3) BPP_FOOT(2, 4) BPP_FOOT(2, 5)
+                        BPP_FOOT(3, 2) BPP_FOOT(3, 3) BPP_FOOT(3, 4) BPP_FOOT(3, 5)
+                        BPP_FOOT(4, 2) BPP_FOOT(4, 3) BPP_FOOT(4, 4) BPP_FOOT(4, 5)
+                        BPP_FOOT(5, 2) BPP_FOOT(5, 3) BPP_FOOT(5, 4) BPP_FOOT(5, 5)
+                        default: break;
+                    }
+    #undef BPP_FOOT
+                } else {
+                    run(FF{}, FF{}, I0{}, I0{});
+                }
                 wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
             }
             anymask |= tot > 0 ? 1u << b : 0u;

@@ -21,13 +21,34 @@ from .spaces import Box, Discrete
 
 
 class StepTensors(object):
-    """Device-resident result of one lock-step (views of the env's output buffers unless the env was
-    built with fresh_outputs=True)."""
-    __slots__ = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small", "_offs", "_stage", "_hot")
+    """Device-resident result of one lock-step (views of the env's output buffers unless the env was built with
+    fresh_outputs=True).  Either built from ready tensors (keyword arguments), or -- what the env does -- over ONE flat
+    device allocation with a layout {name: (byte offset, dtype, shape)}: the views are then made on first use, so a
+    step that nobody inspects beyond `obs` costs one allocation and one view."""
+    FIELDS = ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len", "_small")
+    __slots__ = FIELDS + ("_offs", "_stage", "_hot", "_flat", "_layout")
 
-    def __init__(self, **kw):
-        for k in self.__slots__:
-            setattr(self, k, kw.get(k))
+    def __init__(self, _flat=None, _layout=None, **kw):
+        self._flat, self._layout = _flat, _layout
+        self._offs, self._stage, self._hot = kw.pop("_offs", None), kw.pop("_stage", None), kw.pop("_hot", None)
+        if _flat is None:
+            for k in self.FIELDS:
+                setattr(self, k, kw.get(k))
+
+    def __getattr__(self, name):            # only reached for a slot that has not been filled yet: make the view
+        lay = object.__getattribute__(self, "_layout") if name in StepTensors.FIELDS else None
+        if lay is None:
+            raise AttributeError(name)
+        ent = lay.get(name)
+        v = None
+        if ent is not None:
+            off, dtype, shape, nbytes = ent
+            v = self._flat[off:off + nbytes].view(dtype).view(shape)
+        setattr(self, name, v)
+        return v
+
+    def __getitem__(self, name):            # bufs["obs"] of older call sites
+        return getattr(self, name)
 
     @property
     def masks(self):
@@ -295,37 +316,48 @@ class BppVecEnv(object):
         self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
         self._tstart = time.time()
-        self.location_masks = None
         self.closed = False
 
     # ------------------------------------------------------------------ buffers
+    def _layout(self):
+        """Byte layout of one set of output buffers inside a single allocation (every region 256-byte aligned): obs,
+        mask, then the six small per-bin outputs as one block whose first part -- reward and done, 5 bytes per bin -- is
+        all the reference-shaped step_wait() copies to the host."""
+        lay = getattr(self, "_lay", None)
+        if lay is None:
+            E, total, regions = self.E, 0, {}
+
+            def add(name, dtype, shape, width):
+                nonlocal total
+                n = 1
+                for d in shape:
+                    n *= d
+                regions[name] = (total, dtype, shape, n * width)
+                return n * width
+
+            total += (add("obs", torch.float32, (E, self.obs_len), 4) + 255) // 256 * 256
+            if self.compute_mask:
+                total += (add("mask", torch.float32, (E, self.M), 4) + 255) // 256 * 256
+            small0, offs, hot = total, {}, 0
+            for name, dtype, shape, width in (("reward", torch.float32, (E, 1), 4), ("done", torch.uint8, (E,), 1),
+                                              ("ratio", torch.float64, (E,), 8), ("ep_ret", torch.float64, (E,), 8),
+                                              ("counter", torch.int32, (E,), 4), ("ep_len", torch.int32, (E,), 4)):
+                offs[name] = total - small0
+                total += (add(name, dtype, shape, width) + 7) // 8 * 8
+                if name == "done":
+                    hot = total - small0
+            regions["_small"] = (small0, torch.uint8, (total - small0,), total - small0)
+            lay = self._lay = (regions, total, offs, hot)
+        return lay
+
     def _alloc(self):
-        E, dev = self.E, self.device
-        # the six small per-bin outputs live in ONE byte buffer (8-byte aligned slices); reward and done come first:
-        # that prefix (5 bytes per bin) is all the reference-shaped step_wait() copies to the host
-        offs, total, hot = {}, 0, 0
-        for name, width in (("reward", 4), ("done", 1), ("ratio", 8), ("ep_ret", 8), ("counter", 4), ("ep_len", 4)):
-            offs[name] = total
-            total += (E * width + 7) // 8 * 8
-            if name == "done":
-                hot = total
-        small = torch.empty((total,), dtype=torch.uint8, device=dev)
-
-        def view(name, dtype, width):
-            return small[offs[name]:offs[name] + E * width].view(dtype)
-
-        b = dict(obs=torch.empty((E, self.obs_len), dtype=torch.float32, device=dev),
-                 mask=torch.empty((E, self.M), dtype=torch.float32, device=dev) if self.compute_mask else None,
-                 reward=view("reward", torch.float32, 4).view(E, 1),
-                 done=view("done", torch.uint8, 1),
-                 counter=view("counter", torch.int32, 4),
-                 ratio=view("ratio", torch.float64, 8),
-                 ep_ret=view("ep_ret", torch.float64, 8),
-                 ep_len=view("ep_len", torch.int32, 4))
-        out = _lib.StepOut(*[(b[k].data_ptr() if b[k] is not None else None)
+        regions, total, offs, hot = self._layout()
+        flat = torch.empty((total,), dtype=torch.uint8, device=self.device)
+        base = flat.data_ptr()
+        res = StepTensors(_flat=flat, _layout=regions, _offs=offs, _stage=self._staging, _hot=hot)
+        out = _lib.StepOut(*[(base + regions[k][0] if k in regions else None)
                              for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
-        b["_small"], b["_offs"], b["_stage"], b["_hot"] = small, offs, self._staging, hot
-        return b, out
+        return res, out
 
     def _staging(self):
         """A page-locked host buffer (numpy uint8 view) for the per-bin scalars of a step that nobody else references:
@@ -334,7 +366,7 @@ class BppVecEnv(object):
         and done into its rollout storage at once, so two or three buffers circulate."""
         import sys
         pool = getattr(self, "_stage_pool", None)
-        n = self._bufs["_small"].numel() if self._bufs is not None else 0
+        n = self._layout()[0]["_small"][3]
         if pool is None or (pool and pool[0][1].size != n):
             pool = self._stage_pool = []
         for k, (t, a) in enumerate(pool):
@@ -374,12 +406,17 @@ class BppVecEnv(object):
         if torch.cuda.current_device() != self.device.index:
             torch.cuda.set_device(self.device)
 
+    @property
+    def location_masks(self):
+        """float32 [E][M] feasibility mask of the current observations (None before the first reset / without compute_mask)."""
+        return self._res.mask if self._res is not None else None
+
     # ------------------------------------------------------------------ VecEnv interface
     def reset(self):
         """All bins start a fresh episode (next sequence of their stride); returns obs [E,4A] float32."""
         self._on_device()
         bufs, out = self._buffers()
-        self._res = StepTensors(**bufs)
+        self._res = bufs
         mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
         if self._stream is not None and not self._first_reset:
             self.refill()              # RESET_ADVANCE moves every bin on by one episode
@@ -388,7 +425,6 @@ class BppVecEnv(object):
         self._stepped()
         self._first_reset = False
         self._tstart = time.time()
-        self.location_masks = bufs["mask"]
         return bufs["obs"]
 
     def step_tensors(self, actions, sample=None):
@@ -409,8 +445,7 @@ class BppVecEnv(object):
         self._on_device()
         if self.fresh_outputs or self._bufs is None:
             self._bufs, self._out = self._alloc()
-            self._res = StepTensors(**self._bufs)
-            self.location_masks = self._bufs["mask"]
+            self._res = self._bufs
         out = self._out
         if sample is not None:
             seed, step, nxt = sample
@@ -477,8 +512,7 @@ class BppVecEnv(object):
                                                      _lib.ROLLOUT_CONTINUE if resume else 0, self._stream_ptr()))
         if nsteps > 0:
             self._bufs, self._out = sets[(int(nsteps) - 1) % n]
-            self._res = StepTensors(**self._bufs)
-            self.location_masks = self._bufs["mask"]
+            self._res = self._bufs
         return self._res
 
     def step_async(self, actions):
@@ -650,12 +684,11 @@ class BppVecEnv(object):
         if "obs" in sd:
             bufs, _ = self._buffers()
             if self._res is None or self.fresh_outputs:
-                self._res = StepTensors(**bufs)
+                self._res = bufs
             bufs["obs"].copy_(sd["obs"])
             if "mask" in sd and bufs["mask"] is not None:
                 bufs["mask"].copy_(sd["mask"])
-                self.location_masks = bufs["mask"]
-
+        
     def state_numpy(self):
         """bpp_env_state[E] as a structured numpy array (tests)."""
         dt = np.dtype([("cursor", "<i4"), ("episode", "<i4"), ("n_boxes", "<i4"), ("vol_sum", "<i4"),

@@ -42,7 +42,7 @@ def main():
             def run(n, t0):
                 for t in range(t0, t0 + n):
                     env._bufs, env._out = sets[t % R]
-                    env._res = StepTensors(**env._bufs)
+                    env._res = env._bufs
                     env.step_tensors(actions, sample=(1, t + 1, actions))
 
             run(60, 0)
