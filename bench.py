@@ -118,6 +118,12 @@ def cpu_baseline(pool, size, rotation, seconds):
         res = pw.map(_cpu_worker, jobs)
     rate = sum(bins * n / dt for n, dt in res)     # every worker measured over its own busy interval
     return {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "reference_subprocvecenv_timed_here": False,
+            "why_not": "north_star's baseline is the reference's own SubprocVecEnv / ShmemVecEnv plumbing (acktr/envs.py:77-118, parent-side "
+                       "mask loop main.py:163-169); the reference tree does not exist on the GPU box, so what is timed in this run is "
+                       "(1) this C port of the same step + mask and (2) `python_port`, a Python / numpy restatement of one reference worker "
+                       "and the parent's mask loop; the unmodified reference's own throughput was measured in the build container only "
+                       "(`reference_python_context`)",
             "single_core_value": single, "python_port": python_port_baseline(pool, size, rotation, cores, 0.4 * seconds),
             "reference_python_context": reference_python_context(),
             "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "

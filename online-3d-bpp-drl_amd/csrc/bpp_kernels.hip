@@ -592,10 +592,14 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
     ma = 0;
     // (rare path -- items wider than 5 x 6, in the benchmark only the bin-sized terminator: kept rolled, an unrolled
     // copy of these loops was what set the kernels' scalar-register count and cost the 10x10 + rotation kernel a workgroup slot per CU)
+#ifndef BPP_EXP_UNROLL_BIG
 #pragma unroll 1
+#endif
     for (int a0 = 0; a0 < x; a0 += kTileX) {
         const int xa = min(kTileX, x - a0);
+#ifndef BPP_EXP_UNROLL_BIG
 #pragma unroll 1
+#endif
         for (int b0 = 0; b0 < y; b0 += kTileY) {
             const int yb = min(kTileY, y - b0);
             int m, c;
@@ -2040,7 +2044,7 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
         const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M);
         const int off_bal = (off_rec + nbw * (int)sizeof(TileRec) + 7) & ~7;
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
-        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K);
+        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K + BPP_TILE_LDS_PAD);
         out[2] = nbw;
     }
     out[5] = (int32_t)lds;

@@ -34,6 +34,14 @@ constexpr CandMagicTable make_cand_magic() {
 __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
+// experiment switches of tools/build_variant.sh (defaults = the product): length-specialised candidate loops on / off,
+// extra LDS bytes per wave (lowers the number of workgroups a CU holds)
+#ifndef BPP_TILE_SPEC
+#define BPP_TILE_SPEC 1
+#endif
+#ifndef BPP_TILE_LDS_PAD
+#define BPP_TILE_LDS_PAD 0
+#endif
 
 // Constants of one (bin, orientation) of the item on display: computed lane-parallel for all the wave's bins at once
 // (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
@@ -46,7 +54,12 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 //   w6: hash32(seed, global bin id, step) of the fused draw
 // Per-bin record in LDS written by the deciding wave (or, in the mask-only modes, by the owning wave), read by the
 // bin's lanes: 12 bytes.
+#ifdef BPP_EXP_REC16
+struct __attribute__((aligned(16))) TileRec {
+    uint32_t pad_;
+#else
 struct TileRec {
+#endif
     uint32_t item;   // item shown in the next observation: x | y<<8 | z<<16
     uint32_t place;  // lx | ly<<8 | x<<16 | y<<24 of the box just placed
     uint32_t flags;  // bit0 placed, bit1 reset (zero the map), bit2 every height of the bin <= kLowTop, bits 8.. new top height
@@ -95,7 +108,7 @@ struct TileGeo {
     // workgroups per CU, the 10x10 + rotation one <= 20 480 for eight -- it is exactly 20 480)
     static constexpr int OFF_BAL = (OFF_REC + NBW * (int)sizeof(TileRec) + 7) & ~7;   // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
-    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K;                    // prefix image of the current group
+    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K + BPP_TILE_LDS_PAD;  // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
     static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
     static_assert(G <= A4, "a lane group must not span more than two observation planes per pass");
@@ -636,21 +649,24 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     continue;
                 }
                 if (!valid) continue;                                       // item does not fit at all
-                // One candidate loop per case, so that no bin-uniform condition is re-tested per candidate.  XC, YC != 0:
-                // the loop compiled for ONE item footprint -- every offset of the four prefix-image reads and the four
-                // corner reads is then an immediate, the thresholds and the index decode are literals, and a second pass
-                // exists only where (W - x + 1)(L - y + 1) > 64.  The sixteen footprints 2..5 x 2..5 are what CUT-2 / RS
-                // sequences consist of (acktr/arguments.py:122-128); anything else runs the XC = 0 form.
-                auto run = [&](auto big_c, auto empty_c, auto xc_c, auto yc_c) {
+                // One candidate loop per case, so that no bin-uniform condition is re-tested per candidate.  YC != 0: the
+                // loop compiled for ONE item length y -- the y-offsets of the prefix-image and corner reads are then
+                // immediates (two address additions instead of six) and the index decode is a literal.  Used where a wave
+                // owns ONE bin and runs five or six passes through the same loop (20x20: 61.4 -> 58.7 us); with four bins per
+                // wave every wave hops between the variants and the instruction cache loses more than the additions cost
+                // (10x10: 28.3 -> 28.8 us, + rotation 34.8 -> 36.7 us; one loop per footprint x * y, sixteen variants with
+                // every offset immediate, 19 -> 32 KB of code for the rotation kernel: 37.7 -> 40.9 us).  The lengths 2..5
+                // are what CUT-2 / RS sequences consist of (acktr/arguments.py:122-128); anything else runs the YC = 0 form.
+                auto run = [&](auto big_c, auto empty_c, auto yc_c) {
                     constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
-                    constexpr int XC = decltype(xc_c)::value, YC = decltype(yc_c)::value;
-                    constexpr bool SP = XC != 0;
-                    constexpr int cNJ = SP ? L - YC + 1 : 1, cNV = SP ? (W - XC + 1) * cNJ : 0, cAREA = XC * YC;
+                    constexpr int YC = decltype(yc_c)::value;
+                    constexpr bool SP = YC != 0;
+                    constexpr int cNJ = SP ? L - YC + 1 : 1;
                     constexpr uint32_t cOD = ((1u << kCandShift) + (uint32_t)cNJ - 1u) / (uint32_t)cNJ;
-                    const int c_nv = SP ? cNV : nv, c_nj = SP ? cNJ : nj, c_y = SP ? YC : y, c_xPW = SP ? XC * PW : xPW;
+                    const int c_nv = nv, c_nj = SP ? cNJ : nj, c_y = SP ? YC : y, c_xPW = xPW;
                     const uint32_t c_od = SP ? cOD : od;
-                    const int c_o10 = SP ? (XC - 1) * L : o10, c_o01 = SP ? YC - 1 : o01;
-                    const int c_t95 = SP ? 19 * cAREA / 20 + 1 : t95, c_t85 = SP ? 17 * cAREA / 20 + 1 : t85, c_t50 = SP ? cAREA / 2 + 1 : t50;
+                    const int c_o10 = o10, c_o01 = SP ? YC - 1 : o01;
+                    const int c_t95 = t95, c_t85 = t85, c_t50 = t50;
     #pragma unroll(BAL_REGS ? NPASS : 1)
                     for (int ps = 0; ps < NPASS; ++ps) {
                         if (ps * kWave >= c_nv) break;                      // wave-uniform (compile-time when SP)
@@ -696,24 +712,22 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 using TT = std::true_type;
                 using FF = std::false_type;
                 using I0 = std::integral_constant<int, 0>;
-                // footprint-specialised loops: the BASELINE geometries' step and mask kernels (resets only see empty maps)
-                constexpr bool kSpec = ((W == 10 && L == 10 && K == 1) || (W == 20 && L == 20 && K == 2)) && !kResetsOnly;
+                // length-specialised loops: the 20x20x20 step and mask kernels (resets only see empty maps)
+                constexpr bool kSpec = BPP_TILE_SPEC && EPW == 1 && W == 20 && L == 20 && K == 2 && !kResetsOnly;
                 if (fresh) {
-                    run(FF{}, TT{}, I0{}, I0{});
+                    run(FF{}, TT{}, I0{});
                 } else if (big) {
-                    run(TT{}, FF{}, I0{}, I0{});
-                } else if (kSpec && (uint32_t)(x - 2) < 4u && (uint32_t)(y - 2) < 4u) {
-    #define BPP_FOOT(X, Y) case (X) * 8 + (Y): run(FF{}, FF{}, std::integral_constant<int, kSpec ? (X) : 0>{}, std::integral_constant<int, kSpec ? (Y) : 0>{}); break;
-                    switch (x * 8 + y) {
-                        BPP_FOOT(2, 2) BPP_FOOT(2, 3) BPP_FOOT(2, 4) BPP_FOOT(2, 5)
-                        BPP_FOOT(3, 2) BPP_FOOT(3, 3) BPP_FOOT(3, 4) BPP_FOOT(3, 5)
-                        BPP_FOOT(4, 2) BPP_FOOT(4, 3) BPP_FOOT(4, 4) BPP_FOOT(4, 5)
-                        BPP_FOOT(5, 2) BPP_FOOT(5, 3) BPP_FOOT(5, 4) BPP_FOOT(5, 5)
-                        default: break;
-                    }
-    #undef BPP_FOOT
+                    run(TT{}, FF{}, I0{});
+                } else if (kSpec && y == 2) {
+                    run(FF{}, FF{}, std::integral_constant<int, kSpec ? 2 : 0>{});
+                } else if (kSpec && y == 3) {
+                    run(FF{}, FF{}, std::integral_constant<int, kSpec ? 3 : 0>{});
+                } else if (kSpec && y == 4) {
+                    run(FF{}, FF{}, std::integral_constant<int, kSpec ? 4 : 0>{});
+                } else if (kSpec && y == 5) {
+                    run(FF{}, FF{}, std::integral_constant<int, kSpec ? 5 : 0>{});
                 } else {
-                    run(FF{}, FF{}, I0{}, I0{});
+                    run(FF{}, FF{}, I0{});
                 }
                 wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
             }
@@ -729,11 +743,11 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 if (tot == 0) {
                     if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
                 } else {
-                    // the winning pass, on the scalar unit: the first (orientation, pass) whose running count exceeds `rem`
+                    // the pick-th set ballot bit, passes in enumeration order.  (A branch-free form of this search --
+                    // scalar selects of the winning (orientation, pass, ballot) -- was measured: 37.5 instead of 34.6 us for
+                    // the rotation kernel; the 64-bit selects and their wait states cost more than the taken branch.)
                     int rem = (int)__umulhi(hsh, (uint32_t)tot);
                     bool found = false;
-                    unsigned long long wbl = 0ull;
-                    int wrot = 0, wps = 0;
     #pragma unroll
                     for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {
     #pragma unroll(BAL_REGS ? NPASS : 1)
@@ -749,27 +763,25 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                 bl = ((unsigned long long)vhi << 32) | (unsigned long long)vlo;
                             }
                             const int c = __popcll(bl);
-                            const bool hit = !found && rem < c;
-                            wbl = hit ? bl : wbl;
-                            wrot = hit ? rot : wrot;
-                            wps = hit ? ps : wps;
-                            found = found || hit;
+                            if (!found && rem < c) {
+                                found = true;
+                                // index decode of this orientation: the slot's first word again
+                                uint32_t od, nj;
+                                if constexpr (EPW > 1) {
+                                    const uint32_t ww0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], b * G + rot);
+                                    od = ww0 & 0xffffffu, nj = ww0 >> 24;
+                                } else {
+                                    od = dec_od[rot], nj = dec_nj[rot];
+                                }
+                                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+                                if (((bl >> lane) & 1ull) && (int)below == rem) {
+                                    const int t = lane + ps * kWave;
+                                    const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * (int)nj;
+                                    p.next_action[e] = (int64_t)(rot * A + i * L + j);
+                                }
+                            }
                             rem -= found ? 0 : c;
                         }
-                    }
-                    // index decode of the winning orientation (the slot's first word again)
-                    uint32_t od, nj;
-                    if constexpr (EPW > 1) {
-                        const uint32_t ww0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], b * G + wrot);
-                        od = ww0 & 0xffffffu, nj = ww0 >> 24;
-                    } else {
-                        od = wrot ? dec_od[ROT ? 1 : 0] : dec_od[0], nj = wrot ? dec_nj[ROT ? 1 : 0] : dec_nj[0];
-                    }
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(wbl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wbl, 0u));
-                    if (((wbl >> lane) & 1ull) && (int)below == rem) {
-                        const int t = lane + wps * kWave;
-                        const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * (int)nj;
-                        p.next_action[e] = (int64_t)(wrot * A + i * L + j);
                     }
                 }
             }
