@@ -555,6 +555,21 @@ __device__ __forceinline__ Ent<K> code_of(uint32_t h) {
     return c;
 }
 
+// One-word codes of a bin whose heights need two words, one word at a time (bpp_tile_kernel's two-phase scan of tall
+// 20x20 bins): PH = 1 -> the upper word (levels 12..23, zero for lower cells), PH = 2 -> the lower word (levels 0..11,
+// zero for higher cells); PH = 0 -> the plain one-word code (every height <= 11).
+template <int PH>
+__device__ __forceinline__ Ent<1> code_phase(uint32_t h) {
+    Ent<1> c;
+    if (PH == 0) {
+        c.w[0] = 1ull << (kFieldBits * h);
+    } else {
+        const uint32_t rel = PH == 1 ? h - (uint32_t)kLevelsPerWord : h;   // wraps to a huge value below the upper word
+        c.w[0] = rel < (uint32_t)kLevelsPerWord ? 1ull << (kFieldBits * rel) : 0ull;
+    }
+    return c;
+}
+
 // Highest non-empty level of a window histogram and the count stored there.
 template <int K>
 __device__ __forceinline__ void top_of(const Ent<K> &h, int &m, int &cnt) {
@@ -572,20 +587,24 @@ __device__ __forceinline__ void top_of(const Ent<K> &h, int &m, int &cnt) {
     m = word * kLevelsPerWord + lvl;
 }
 
-template <int K>
+template <int K, bool ZERO_OK = false>
 __device__ __forceinline__ void rect_top(const Ent<K> *P00, int PW, int xa, int yb, int &m, int &cnt) {
     const Ent<K> a = P00[0], b = P00[yb], c = P00[xa * PW], d = P00[xa * PW + yb];
     Ent<K> h;
 #pragma unroll
     for (int k = 0; k < K; ++k) h.w[k] = d.w[k] - b.w[k] - c.w[k] + a.w[k];
     top_of<K>(h, m, cnt);
+    if (ZERO_OK && K == 1 && h.w[0] == 0ull) {   // no cell of this rectangle has a level in the word scanned: contributes nothing
+        m = -1;
+        cnt = 0;
+    }
 }
 
 // (max_h, max_area) of window [i,i+x) x [j,j+y) from the bin's prefix image (acktr/utils.py:14-16).
-template <int K>
+template <int K, bool ZERO_OK = false>
 __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int j, int x, int y, int &mh, int &ma) {
     if (x <= kTileX && y <= kTileY) {
-        rect_top<K>(Pb + i * PW + j, PW, x, y, mh, ma);
+        rect_top<K, ZERO_OK>(Pb + i * PW + j, PW, x, y, mh, ma);
         return;
     }
     mh = -1;
@@ -603,7 +622,7 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
         for (int b0 = 0; b0 < y; b0 += kTileY) {
             const int yb = min(kTileY, y - b0);
             int m, c;
-            rect_top<K>(Pb + (i + a0) * PW + (j + b0), PW, xa, yb, m, c);
+            rect_top<K, ZERO_OK>(Pb + (i + a0) * PW + (j + b0), PW, xa, yb, m, c);
             ma = m > mh ? c : ma + (m == mh ? c : 0);
             mh = max(mh, m);
         }
@@ -623,7 +642,7 @@ __device__ __forceinline__ Ent<K> shfl_up_ent(const Ent<K> &v, int d) {
     return r;
 }
 
-template <int W, int L, int K>
+template <int W, int L, int K, int PH = 0>
 __device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *P, uint32_t hclamp, int lane) {
     constexpr int PW = L + 1;
     constexpr int SR = (kWave / W) < 1 ? 1 : (kWave / W), CSR = (L + SR - 1) / SR;  // row pass: segments along j
@@ -643,7 +662,9 @@ __device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *
         for (int c = 0; c < CSR; ++c) {
             const int j = j0 + c;
             if (j < L) {
-                const Ent<K> cd = code_of<K>(min((uint32_t)row[j], hclamp));
+                Ent<K> cd;
+                if constexpr (K == 1 && PH != 0) cd = code_phase<PH>(min((uint32_t)row[j], hclamp));
+                else cd = code_of<K>(min((uint32_t)row[j], hclamp));
 #pragma unroll
                 for (int k = 0; k < K; ++k) run.w[k] += cd.w[k];
             }
@@ -2044,7 +2065,7 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
         const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M);
         const int off_bal = (off_rec + nbw * (int)sizeof(TileRec) + 7) & ~7;
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
-        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * g.K + BPP_TILE_LDS_PAD);
+        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * (g.epw == 1 ? 1 : g.K) + BPP_TILE_LDS_PAD);   // TileGeo::KP
         out[2] = nbw;
     }
     out[5] = (int32_t)lds;

@@ -42,6 +42,12 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 #ifndef BPP_TILE_LDS_PAD
 #define BPP_TILE_LDS_PAD 0
 #endif
+#ifndef BPP_TILE_LATE_POOL
+#define BPP_TILE_LATE_POOL 0   // 1: next-step pool entries loaded behind the second barrier (measured: 28.3 -> 28.9 us, stream mode 55.1 -> 57.6 us/lock-step)
+#endif
+#ifndef BPP_EXP_FORCE_LOW
+#define BPP_EXP_FORCE_LOW 0    // 1: TIMING EXPERIMENT ONLY (wrong masks for tall bins): 20x20 always on the one-word path, LDS sized for it
+#endif
 
 // Constants of one (bin, orientation) of the item on display: computed lane-parallel for all the wave's bins at once
 // (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
@@ -108,7 +114,10 @@ struct TileGeo {
     // workgroups per CU, the 10x10 + rotation one <= 20 480 for eight -- it is exactly 20 480)
     static constexpr int OFF_BAL = (OFF_REC + NBW * (int)sizeof(TileRec) + 7) & ~7;   // ballots of the candidate passes
     static constexpr int OFF_P = round16(OFF_BAL + (NPASS > 2 ? EPW * 2 * NPASS * 8 : 0));
-    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * K + BPP_TILE_LDS_PAD;  // prefix image of the current group
+    // A wave that owns ONE bin (20x20) only ever holds a ONE-word prefix image: a bin taller than kLowTop is scanned
+    // in two phases, upper word then lower word, in the same 3.5 KB (8 workgroups per CU instead of 5 with a two-word image).
+    static constexpr int KP = (K == 2 && EPW == 1) ? 1 : K;
+    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * KP + BPP_TILE_LDS_PAD;  // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
     static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
     static_assert(G <= A4, "a lane group must not span more than two observation planes per pass");
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     float out_rew = 0.0f;
     int fin_len = 0, out_boxes = 0;
     bpp_env_state st_out;
+    size_t late_a = 0, late_b = 0;
+    int late_kind = 0;
     if (kDecide && wid == 0 && !BPP_ABL(p, 32)) {
         __builtin_amdgcn_s_setprio(3);                 // the other waves of the workgroup wait for this chain
         const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
@@ -239,9 +250,18 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             int seq_nn = seq_n + p.seq_stride;
             seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
             const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
+#if BPP_TILE_LATE_POOL
+            // The pool entries the NEXT step needs only go into the state record, never into this step's outputs: their
+            // loads are issued behind the second barrier, and only those of the branch taken (a barrier waits for a
+            // wave's outstanding loads -- with a ring pool these are HBM misses, and all four waves waited for them).
+            const size_t pl_ok = (size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1);
+            const size_t pl_f1 = (size_t)seq_n * Tn + min(1, Tn - 1), pl_f2 = (size_t)seq_nn * Tn;
+            const uint32_t sp_ok = 0u, sp_f1 = 0u, sp_f2 = 0u;
+#else
             const uint32_t sp_ok = p.pool[(size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1)];
             const uint32_t sp_f1 = p.pool[(size_t)seq_n * Tn + min(1, Tn - 1)];
             const uint32_t sp_f2 = p.pool[(size_t)seq_nn * Tn];
+#endif
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
@@ -344,7 +364,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 r.item = it_rst;
                 r.flags = 2u | 4u;
             }
-            st_out = st;   // written behind the second barrier (it waits for the speculative pool loads)
+#if BPP_TILE_LATE_POOL
+            late_a = ok ? pl_ok : pl_f1;               // -> item_next (either way); unused for a bin left alone
+            late_b = pl_f2;                            // -> item_reset after a failed placement
+            late_kind = noop ? 0 : (ok ? 1 : 2);
+#endif
+            st_out = st;   // written behind the second barrier
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -419,12 +444,21 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)e, 32);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
+#if BPP_TILE_LATE_POOL
+        uint32_t la = 0u, lb = 0u;
+        if (late_kind != 0) la = p.pool[late_a];
+        if (late_kind == 2) lb = p.pool[late_b];
+#endif
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
         p.counter[e] = out_boxes;
         p.ratio[e] = fin_ratio;
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
+#if BPP_TILE_LATE_POOL
+        if (late_kind != 0) st_out.item_next = la;
+        if (late_kind == 2) st_out.item_reset = lb;
+#endif
         p.state[e] = st_out;
         if (acc) {
             ea[0] = a0 + fin_ret;
@@ -533,14 +567,19 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 low = __ballot(mx > (uint32_t)kLowTop) == 0ull;
             }
         }
+        if (BPP_EXP_FORCE_LOW && K == 2 && EPW == 1) low = true;
+        constexpr bool kTwoPhase = K == 2 && EPW == 1;         // tall bins: two one-word scans instead of one two-word scan
         uint32_t anymask = 0;                                  // bit b: bin b of the group has a feasible position
-        auto phase4 = [&](auto kk_c) {
-        constexpr int KK = decltype(kk_c)::value;
+        // PH = 0: one scan (all levels in the image); 1: first scan of a tall bin -- the image holds the UPPER word, a
+        // candidate whose window reaches into it is decided now, the others get the mask byte 2; 2: second scan -- the image
+        // holds the LOWER word, the candidates marked 2 are decided, ballots / draw / fallback as in a single scan.
+        auto phase4 = [&](auto kk_c, auto ph_c) {
+        constexpr int KK = decltype(kk_c)::value, PH = decltype(ph_c)::value;
         Ent<KK> *P = (Ent<KK> *)(wb + T::OFF_P);               // (shadows the kernel's K-word view of the same bytes)
         // ---- phase 4a: prefix image of the height-level codes ------------------------------------------------
         if (!BPP_ABL(p, 1)) {
             if constexpr (EPW == 1) {
-                if (nenv > 0) build_prefix_one_bin<W, L, KK>(hm, P, hclamp, lane);
+                if (nenv > 0) build_prefix_one_bin<W, L, KK, PH>(hm, P, hclamp, lane);
             } else {
                 Ent<KK> zero;   // (row 0 and column 0 of every image were cleared before the second barrier)
 #pragma unroll
@@ -585,7 +624,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
 
         if (it == 0) BPP_STAMP(p, 8);
         // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94), bin after bin ---------
-        if (it > 0) {   // (the first group's mask bytes were cleared before the second barrier)
+        if (it > 0 && PH != 2) {   // (the first group's mask bytes were cleared before the second barrier)
 #pragma unroll
             for (int k = 0; k < KM; ++k)
                 if (mine && sl + G * k < M4) mk32[el * M4 + sl + G * k] = 0u;
@@ -633,6 +672,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     for (int ps = lane; ps < NPASS; ps += kWave) balm[(b * 2 + rot) * NPASS + ps] = 0ull;
                     wave_sync();
                 }
+                if (PH == 1 && ROT && rot == 1 && square) continue;      // (copied from the first half by the second scan)
                 if (ROT && rot == 1 && square) {
                     // square footprint: the turned item's mask (utils.py:81-89) equals the first half
 #pragma unroll
@@ -674,20 +714,32 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                         bool f = false;
                         if (t < c_nv) {
                             const int i = (int)(((uint32_t)t * c_od) >> kCandShift), j = t - i * c_nj;
+                            uint8_t *mb = me + rot * A + i * L + j;
+                            bool need = true;                      // second scan: only what the first one left open
+                            if (PH == 2) {
+                                const uint32_t prev = *mb;
+                                need = prev == 2u;
+                                f = prev == 1u;
+                            }
                             if (EMPTY) {
                                 f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
-                            } else {
+                                *mb = f ? 1 : 0;
+                            } else if (need) {
                                 const Ent<KK> *Pb = Pe + i * PW + j;
                                 int mh, ma;
+                                bool decided = true;
                                 if (!BIG) {
                                     const Ent<KK> a = Pb[0], bb = Pb[c_y], cc = Pb[c_xPW], d = Pb[c_xPW + c_y];
                                     Ent<KK> h;
     #pragma unroll
                                     for (int k = 0; k < KK; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
                                     top_of<KK>(h, mh, ma);
+                                    if (PH == 1) decided = h.w[0] != 0ull;   // some cell of the window lies in the upper word
                                 } else {
-                                    window_top<KK>(Pe, PW, i, j, x, y, mh, ma);
+                                    window_top<KK, PH != 0>(Pe, PW, i, j, x, y, mh, ma);
+                                    if (PH == 1) decided = mh >= 0;
                                 }
+                                if (PH == 1) mh += kLevelsPerWord;
                                 const uint8_t *hb = he + i * L + j;
                                 const int r00 = hb[0], r10 = hb[c_o10], r01 = hb[c_o01], r11 = hb[c_o10 + c_o01];
                                 // utils.py:23-33 on lane masks: all four corners at max_h -> t50, exactly three -> t85
@@ -700,9 +752,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                     const int rm = max(max(r00, r10), max(r01, r11));
                                     f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
                                 }
+                                *mb = (PH == 1 && !decided) ? 2 : (f ? 1 : 0);
                             }
-                            me[rot * A + i * L + j] = f ? 1 : 0;
                         }
+                        if (PH == 1) continue;                     // no ballots before every candidate is decided
                         const unsigned long long bl = __ballot(f);
                         tot += __popcll(bl);
                         if (BAL_REGS) balr[rot][ps] = bl;
@@ -731,6 +784,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 }
                 wave_sync();   // reconvergence point of the candidate loop (also orders the LDS ballots)
             }
+            if (PH == 1) continue;                                 // fallback flag and draw belong to the second scan
             anymask |= tot > 0 ? 1u << b : 0u;
 
             // ---- phase 4c (optional): draw the next action uniformly among the feasible entries -------------
@@ -788,8 +842,17 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
         wave_sync();
         };   // phase4
-        if (low) phase4(std::integral_constant<int, 1>{});
-        else phase4(std::integral_constant<int, K>{});
+        using I0_ = std::integral_constant<int, 0>;
+        if constexpr (kTwoPhase) {
+            if (low) {
+                phase4(std::integral_constant<int, 1>{}, I0_{});
+            } else {
+                phase4(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                phase4(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            }
+        } else {
+            phase4(std::integral_constant<int, K>{}, I0_{});
+        }
 
         if (it == 0) BPP_STAMP(p, 9);
         // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------------
