@@ -62,6 +62,10 @@ def parse():
                     help="auto: --gpus N > 1 started without torch.distributed.run launches its N ranks itself; spawn: do "
                          "that for N = 1 as well")
     ap.add_argument("--no-past-l3", action="store_true", help="skip the rotating-output-sets (HBM-only) leg")
+    ap.add_argument("--past-l3-only", action="store_true",
+                    help="profiling aid: every timed region writes rotating output sets, so that a rocprofv3 kernel "
+                         "summary of this command averages past-the-Infinity-Cache launches only (the JSON line is then "
+                         "that leg's and says so)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -304,7 +308,12 @@ def main():
             state["primed"] = True
         state["t"] += n
 
-    drive(args.warmup)
+    only_sets = None
+    if args.past_l3_only and not args.stream:
+        sb = E * (16 * A + 4 * M + 29)
+        only_sets = env.output_sets(max(3, int(1.07e9 / sb) + 1))
+        args.no_past_l3 = True
+    drive(args.warmup, only_sets)
     stats.collect(env).all_reduce()   # also loads the few torch kernels the collection uses
     stats.zero_()
     # timed region = EXACTLY K lock-steps: barrier + synchronize, clock, K lock-steps, synchronize, clock (the maximum
@@ -341,7 +350,7 @@ def main():
         samples += [timed_region(sets, log) for _ in range(more)]
         return all_max(samples)
 
-    samples = repeat_for(0.21)
+    samples = repeat_for(0.21, only_sets)
     reps = len(samples)
     dt = sorted(samples)[len(samples) // 2]
     stats.collect(env).all_reduce()   # whatever finished since the last logging point (outside the timed regions)
@@ -370,7 +379,7 @@ def main():
         state["t"] += len(evs)
         kern_avg_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
     else:
-        kern_avg_ms = sorted(event_timed(n_ev) for _ in range(3))[1]
+        kern_avg_ms = sorted(event_timed(n_ev, only_sets) for _ in range(3))[1]
 
     # ---- past the Infinity Cache: the same lock-steps writing R rotating output sets (> 1 GB span), so that no output
     # byte can stay in the 256 MiB L3 -- the HBM-only figure next to the headline (one 133 MB set fits the L3)
@@ -428,8 +437,9 @@ def main():
             # the same lock-steps with the outputs rotated over > 1 GB: nothing stays in the 256 MiB Infinity Cache
             "value_past_l3": past["value"] if past else None,
             "past_l3": past,
-            "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy"
-                                   % (size + (" + rotation" if args.rotation else "", E)),
+            "config": {"workload": "%dx%dx%d bin, CUT-2 sequences%s, %d envs per MI355X, uniform-random-feasible policy%s"
+                                   % (size + (" + rotation" if args.rotation else "", E,
+                                              " [--past-l3-only: EVERY region writes rotating output sets]" if only_sets else "")),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
                        "pool_source": ("device stream: random.Random(g) per bin, ring of %d rows, refill every %d lock-steps%s (bpp_stream)"
                                        % (args.stream_depth, args.stream_refill,

@@ -735,6 +735,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                     for (int k = 0; k < KK; ++k) h.w[k] = (a.w[k] + d.w[k]) - (bb.w[k] + cc.w[k]);
                                     top_of<KK>(h, mh, ma);
                                     if (PH == 1) decided = h.w[0] != 0ull;   // some cell of the window lies in the upper word
+                                    // (leaving a pass of the first scan early when none of its windows reaches the upper
+                                    // word was measured: 56.8 vs 56.7 us -- nothing)
                                 } else {
                                     window_top<KK, PH != 0>(Pe, PW, i, j, x, y, mh, ma);
                                     if (PH == 1) decided = mh >= 0;

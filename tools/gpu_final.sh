@@ -1,50 +1,69 @@
 #!/bin/bash
-# The round's evidence set for the current build: tools/gpu_measure.sh <tag> (suite, benches, rocprofv3 stats, PMC,
-# sweep) plus phase timelines, the stream-mode bench and the multi-rank bench paths on one device.
+# Round evidence set for the current build, one gpurun call -> gpurun_out/<tag>/ (copy what is to be judged into
+# profiles/ as r3_*): GPU suite, benches of the three single-GPU configs (+ the driver's --steps 20, + the primary pool),
+# rocprofv3 kernel stats per config (headline leg and past-the-Infinity-Cache leg separately), PMC passes per config,
+# mask / reset kernels, drop-in step(), statistics stress (product and legacy-atomics build), stream-supply benches,
+# 2 ranks on one device without a launcher, RCCL with one rank, bins sweep, phase timelines (ablation build).
+# usage: tools/gpu_final.sh <tag>
 set -u
+export TMPDIR=/tmp
 TAG=${1:-final}
 R=/root/repo
 O=$R/gpurun_out/$TAG
+mkdir -p $O
 cd $R
-tools/gpu_measure.sh $TAG
-export TMPDIR=/tmp
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --rotation > $O/bench_rotation.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --size 20 20 20 --envs 32768 --pool 2048 > $O/bench_20x20x20.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --pool-file tests/golden/cut2_dataset_10.npz > $O/bench_primary_pool_cut2_dataset.json 2>> $O/bench.err
+for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768 --pool 2048"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  for leg in "headline:--no-past-l3" "past_l3:--past-l3-only"; do
+    lname=${leg%%:*}; largs=${leg#*:}
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${name}_$lname -o run -- \
+        python $R/bench.py --no-cpu-baseline $largs $args > $O/bench_under_rocprof_${name}_$lname.json 2>/dev/null)
+    cp $O/prof_${name}_$lname/run_kernel_stats.csv $O/kernel_stats_${name}_$lname.csv 2>/dev/null
+    rm -rf $O/prof_${name}_$lname
+  done
+  BENCH_EXTRA="--no-past-l3 --reps 3" tools/profile_pmc.sh ${TAG}_$name $args > /dev/null 2>&1
+  cp $R/gpurun_out/pmc_${TAG}_$name/summary.txt $O/pmc_summary_$name.txt 2>/dev/null
+done
+python tools/pmc_to_json.py 10x10x10_rot0_E65536=$O/pmc_summary_10.txt 10x10x10_rot1_E65536=$O/pmc_summary_10rot.txt \
+    20x20x20_rot0_E32768=$O/pmc_summary_20.txt > /dev/null 2>> $O/bench.err
+cp profiles/hbm_traffic.json $O/hbm_traffic.json
+python tools/bench_mask_kernels.py > $O/mask_and_reset_kernels.json 2>> $O/bench.err
+python tools/bench_dropin_step.py > $O/dropin_step.json 2>> $O/bench.err
+timeout 600 python tools/stress_stats.py --launches 12000 > $O/stress_stats_product.json 2> $O/stress.err
+if [ -f $R/online-3d-bpp-drl_amd/csrc/libbpp_hip_legacystats.so ]; then
+  BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_legacystats.so timeout 600 python tools/stress_stats.py --launches 20000 > $O/stress_stats_legacy_atomics.json 2>> $O/stress.err
+fi
+for cfg in "d32_r14:" "d64_r30:--stream-depth 64 --stream-refill 30" "20_d32_r14:--size 20 20 20 --envs 32768"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  python bench.py --no-cpu-baseline --stream $args > $O/bench_stream_$name.json 2>> $O/bench.err
+done
+BPP_STREAM_OVERLAP=0 python bench.py --no-cpu-baseline --stream > $O/bench_stream_d32_r14_serial.json 2>> $O/bench.err
+BPP_BENCH_ONE_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 100 --warmup 20 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_self_launched_one_device.json
+BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --warmup 20 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
+timeout 600 python tools/sweep_bins.py --bins 65536 262144 > $O/sweep_bins_10.jsonl 2> $O/sweep.err
 if [ -f $R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so ]; then
   for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768"; do
     name=${cfg%%:*}; args=${cfg#*:}
     BPP_HIP_LIB=$R/online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so python tools/phase_timeline.py $args > $O/timeline_$name.json 2>> $O/bench.err
   done
 fi
-# endless device-generated supply: ring depth / refill interval variants, serial schedule, plain kernel; kernel stats;
-# refill latency by sequences per bin; instruction counters of the refill kernels
-for cfg in "d8_r5:--stream-depth 8 --stream-refill 5" "d16_r6:--stream-depth 16 --stream-refill 6" "d32_r14:" \
-           "d64_r30:--stream-depth 64 --stream-refill 30" "20_d32_r14:--size 20 20 20 --envs 32768"; do
-  name=${cfg%%:*}; args=${cfg#*:}
-  python bench.py --no-cpu-baseline --stream $args > $O/bench_stream_$name.json 2>> $O/bench.err
+for f in bench bench_steps20 bench_rotation bench_20x20x20 bench_primary_pool_cut2_dataset; do
+  python - <<PY
+import json
+try:
+    d = json.load(open("$O/$f.json")); r = d["roofline"]
+    print("$f: %.1f M env steps/s (%.1f M past L3), %.2f us/lock-step, kernel %.2f us frac %.3f / past L3 %.2f us frac %.3f" % (
+        d["value"] / 1e6, (d["value_past_l3"] or 0) / 1e6, d["ms_per_step"] * 1e3, r["launch_us"], r["frac"], r["launch_us_past_l3"] or 0, r["frac_past_l3"] or 0))
+except Exception as e:
+    print("$f failed", e)
+PY
 done
-BPP_STREAM_OVERLAP=0 python bench.py --no-cpu-baseline --stream > $O/bench_stream_d32_r14_serial.json 2>> $O/bench.err
-BPP_STREAM_LEGACY=1 python bench.py --no-cpu-baseline --stream --stream-depth 8 --stream-refill 5 > $O/bench_stream_d8_r5_plain.json 2>> $O/bench.err
-BPP_STREAM_LEGACY=1 python bench.py --no-cpu-baseline --stream --stream-depth 8 --stream-refill 5 --size 20 20 20 --envs 32768 --steps 100 --warmup 20 > $O/bench_stream_20_d8_r5_plain.json 2>> $O/bench.err
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o run -- \
-    python $R/bench.py --no-cpu-baseline --stream > /dev/null 2>&1)
-cp $O/prof_stream/run_kernel_stats.csv $O/kernel_stats_stream_d32_r14.csv 2>/dev/null
-python tools/bench_stream_refill.py --needs 1 2 4 > $O/refill_latency.jsonl 2>> $O/bench.err
-python tools/bench_stream_refill.py --needs 1 --frac 0.11 >> $O/refill_latency.jsonl 2>> $O/bench.err
-python tools/bench_stream_refill.py --needs 1 2 --size 20 20 20 --envs 32768 >> $O/refill_latency.jsonl 2>> $O/bench.err
-BPP_STREAM_LEGACY=1 python tools/bench_stream_refill.py --needs 1 2 >> $O/refill_latency.jsonl 2>> $O/bench.err
-for pass in "sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
-            "sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM"; do
-  set -- $pass
-  name=$1; shift
-  (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_refill/$name -o p -- \
-      python $R/tools/bench_stream_refill.py --needs 1 --reps 3 > /dev/null 2>&1) || echo "pass $name failed"
-done
-python tools/pmc_summary.py $O/pmc_refill > /dev/null 2>&1
-cp $O/pmc_refill/summary.txt $O/refill_pmc_summary.txt 2>/dev/null
-rm -rf $O/pmc_refill $O/prof_stream
-BPP_BENCH_BACKEND=gloo BPP_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 20 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_gloo_one_device.json
-BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --warmup 20 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
-timeout 600 python tools/sweep_bins.py --size 20 20 20 --bins 32768 131072 > $O/sweep_bins_20.jsonl 2>> $O/sweep.err
-python tools/bench_mask_kernels.py > $O/mask_and_reset_kernels.json 2>> $O/bench.err
-python tools/bench_masked_act.py > $O/masked_act_timing.json 2>> $O/bench.err
-ls $O | head -50
+head -2 $O/kernel_stats_10_headline.csv | cut -c1-200
+ls $O | head -80
