@@ -110,3 +110,23 @@ def test_gpu_box_native_generators_pinned_to_reference_fixtures(ref):
     want = rows(ref, "cut1_10_rot")
     got = pool_rows(sequences.cut1_pool(tuple(m[:3]), len(want), seed=m[10], box_range=tuple(m[3:9]), rotation=True), tuple(m[:3]))
     assert all(got[k][:len(w)] == w for k, w in enumerate(want))
+
+
+def test_from_dataset_fixture_without_the_reference_tree():
+    """sequences.from_dataset on the committed repack of the reference's dataset/cut_2.pt (no /root/reference needed):
+    LoadBoxCreator's pre-incremented index -> pool row r is trajectory r + 1 (wrapping), rows end in the terminator,
+    every trajectory fills the 10^3 bin exactly (a CUT-2 property)."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "cut2_dataset_10.npz")
+    raw = np.load(path)["pool"]
+    pool = sequences.from_dataset(path, (10, 10, 10))
+    assert pool.shape == raw.shape == (2100, 48, 4)
+    np.testing.assert_array_equal(pool[0], raw[1])
+    np.testing.assert_array_equal(pool[-1], raw[0])
+    np.testing.assert_array_equal(sequences.from_dataset(path, first_index=0), raw)
+    term = (pool[:, :, 0] == 10) & (pool[:, :, 1] == 10) & (pool[:, :, 2] == 10)
+    assert term[:, -1].all()
+    vol = (pool[:, :, 0].astype(int) * pool[:, :, 1] * pool[:, :, 2] * ~term).sum(1)
+    assert (vol == 1000).all()
+    with pytest.raises(ValueError):
+        sequences.from_dataset(path, terminator=(9, 9, 9))
