@@ -52,8 +52,8 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 // Constants of one (bin, orientation) of the item on display: computed lane-parallel for all the wave's bins at once
 // (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
 // candidate loop with v_readlane -- no LDS round trip, ~100 scalar instructions per bin saved.
-//   w0: index-decode multiplier ceil(2^22 / nj) (23 bits) | nj << 24
-//   w1: nv (candidates, 11 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
+//   w0: index-decode multiplier ceil(2^22 / nj) (23 bits)
+//   w1: nv (candidates, 11 bits) | nj << 11 (5 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
 //   w2: x * PW entries (prefix-image row offset) | y << 16
 //   w3: (x - 1) * L (corner offset) | (y - 1) << 16
 //   w4: t95 | t85 << 16          w5: t50 | x << 16 | y << 24
@@ -92,8 +92,10 @@ __device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fre
     const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
     const bool big = x > kTileX || y > kTileY;
     const bool square = rot_kernel && rot == 1 && x == y && valid;
-    w[0] = kCandMagic.v[nj] | ((uint32_t)nj << 24);
-    w[1] = (uint32_t)nv | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) | ((uint32_t)square << 31);
+    // w0 is the table entry AS LOADED -- nothing is computed from it here, so that the load's latency is only waited for
+    // where the candidate loop reads the word (behind the observation store and the prefix image), not in this phase
+    w[0] = kCandMagic.v[nj];
+    w[1] = (uint32_t)nv | ((uint32_t)nj << 11) | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) | ((uint32_t)square << 31);
     w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
     w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
     w[4] = t95 | (t85 << 16);
@@ -120,6 +122,7 @@ struct TileGeo {
     static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * KP + BPP_TILE_LDS_PAD;  // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
     static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
+    static_assert(L + 1 <= 32 && A < 2048, "slot word w1 holds nj in 5 bits and nv in 11");
     static_assert(G <= A4, "a lane group must not span more than two observation planes per pass");
     static_assert(NB <= kWave && LPB >= 1 && (EPW & (EPW - 1)) == 0 && (NIT & (NIT - 1)) == 0, "bins per workgroup");
 };
@@ -656,8 +659,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                     w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4], w5 = ww[5];
                     if (rot == 0 && draw) hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + b));
                 }
-                const uint32_t od = w0 & 0xffffffu;
-                const int nj = (int)(w0 >> 24), nv = (int)(w1 & 0xffffu), hz1 = (int)((w1 >> 16) & 0x1ffu);
+                const uint32_t od = w0;
+                const int nj = (int)((w1 >> 11) & 31u), nv = (int)(w1 & 0x7ffu), hz1 = (int)((w1 >> 16) & 0x1ffu);
                 const bool valid = (w1 >> 28) & 1u, big = (w1 >> 29) & 1u, fresh = (w1 >> 30) & 1u, square = (w1 >> 31) & 1u;
                 const int xPW = (int)(w2 & 0xffffu), y = (int)(w2 >> 16), x = (int)((w5 >> 16) & 255u);
                 const int o10 = (int)(w3 & 0xffffu), o01 = (int)(w3 >> 16);
@@ -824,8 +827,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                                 // index decode of this orientation: the slot's first word again
                                 uint32_t od, nj;
                                 if constexpr (EPW > 1) {
-                                    const uint32_t ww0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], b * G + rot);
-                                    od = ww0 & 0xffffffu, nj = ww0 >> 24;
+                                    od = (uint32_t)__builtin_amdgcn_readlane(slotw[0], b * G + rot);
+                                    nj = ((uint32_t)__builtin_amdgcn_readlane(slotw[1], b * G + rot) >> 11) & 31u;
                                 } else {
                                     od = dec_od[rot], nj = dec_nj[rot];
                                 }
