@@ -61,27 +61,31 @@ class StepTensors(object):
         environment -- like the reference's PackingGame -- never produces."""
         return torch.ones((self.done.numel(), 1), dtype=torch.float32, device=self.done.device)
 
-    def _to_host(self, nbytes):
+    def _to_host(self, nbytes, stream=None):
         """The first `nbytes` of the per-bin scalar block as a numpy byte array in page-locked host memory (a pageable
         destination runs at a fraction of the link's speed).  One native call: hipMemcpyAsync behind the step + stream
         synchronise (bpp_fetch_to_host).  The array is a view of a staging buffer that the env hands out again only
         once nobody holds a view of it any more, so whatever is built on it stays valid for as long as it is referenced."""
-        if self._stage is not None:
+        if self._stage is not None and self._flat is not None:
             host = self._stage()
-            dev = self._small.device
-            _lib.check(_lib.lib().bpp_fetch_to_host(self._small.data_ptr(), host.ctypes.data, int(nbytes),
-                                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            if stream is None:
+                stream = ctypes.c_void_p(torch.cuda.current_stream(self._flat.device).cuda_stream)
+            rc = _lib.lib().bpp_fetch_to_host(self._flat.data_ptr() + self._layout["_small"][0], host.ctypes.data, int(nbytes), stream)
+            if rc:
+                _lib.check(rc)
             return host[:nbytes]
         return self._small[:nbytes].cpu().numpy()
 
-    def host_reward_done(self):
+    def host_reward_done(self, stream=None):
         """(reward float32 [E], done uint8 [E]) with ONE small device->host copy (5 bytes per bin): all the
-        reference-shaped step() needs before anybody looks at `infos`."""
-        E = self.done.numel()
-        if self._small is None:
+        reference-shaped step() needs before anybody looks at `infos`.  `stream`: the stream the step was launched on
+        (c_void_p; default: the device's current stream)."""
+        if self._flat is None:
+            E = self.done.numel()
             return self.reward.cpu().numpy().reshape(E), self.done.cpu().numpy()
         o = self._offs
-        h = self._to_host(self._hot)
+        E = self._layout["done"][3]
+        h = self._to_host(self._hot, stream)
         return h[o["reward"]:o["reward"] + 4 * E].view("<f4"), h[o["done"]:o["done"] + E]
 
     def host_scalars(self):
@@ -313,6 +317,7 @@ class BppVecEnv(object):
         self._out = None
         self._res = None
         self._first_reset = True
+        self._last_stream = None
         self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
         self._tstart = time.time()
@@ -355,8 +360,11 @@ class BppVecEnv(object):
         flat = torch.empty((total,), dtype=torch.uint8, device=self.device)
         base = flat.data_ptr()
         res = StepTensors(_flat=flat, _layout=regions, _offs=offs, _stage=self._staging, _hot=hot)
-        out = _lib.StepOut(*[(base + regions[k][0] if k in regions else None)
-                             for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")])
+        ptr_offs = getattr(self, "_ptr_offs", None)
+        if ptr_offs is None:
+            ptr_offs = self._ptr_offs = [(regions[k][0] if k in regions else None)
+                                         for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+        out = _lib.StepOut(*[(base + o if o is not None else None) for o in ptr_offs])
         return res, out
 
     def _staging(self):
@@ -437,9 +445,9 @@ class BppVecEnv(object):
         a = actions
         if not torch.is_tensor(a):
             a = torch.as_tensor(np.asarray(a))
-        a = a.reshape(-1)
         if a.numel() != self.E:
             raise ValueError("expected %d actions, got %d" % (self.E, a.numel()))
+        # ([E] and [E,1] contiguous tensors share their memory layout: no reshape needed)
         if a.device != self.device or a.dtype != torch.int64 or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.int64).contiguous()
         self._on_device()
@@ -453,11 +461,13 @@ class BppVecEnv(object):
                 raise ValueError("sample out tensor must be a contiguous int64 [E] tensor on the env's device")
             out = _lib.StepOut.from_buffer_copy(self._out)
             out.next_action, out.sample_seed, out.sample_step = nxt.data_ptr(), int(seed), int(step)
-        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), self._stream_ptr())
+        self._last_stream = sp = self._stream_ptr()
+        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
         if rc:
             _lib.check(rc)
         self._serial += 1
-        self._stepped()
+        if self._stream is not None:
+            self._stepped()
         return self._res
 
     def rollout_uniform(self, seed, step0, nsteps, actions=None):
@@ -523,7 +533,7 @@ class BppVecEnv(object):
         r, self._pending = self._pending, None
         if r is None:
             raise RuntimeError("step_wait() without step_async()")
-        rew, done = r.host_reward_done()            # ONE device->host copy: 5 bytes per bin
+        rew, done = r.host_reward_done(self._last_stream)   # ONE device->host copy: 5 bytes per bin
         done = done.view(np.bool_)                  # the kernels write exactly 0 / 1
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)

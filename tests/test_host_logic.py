@@ -118,3 +118,37 @@ def test_threshold_magic_division_is_exact():
         for k in (17, 19):
             n = k * area
             assert n * 0xCCCD < 2 ** 32 and (n * 0xCCCD) >> 20 == n // 20
+
+
+def test_step_tensors_over_one_flat_allocation_makes_views_lazily():
+    """BppVecEnv's output sets are ONE allocation; StepTensors creates each view on first use (a step that only looks
+    at `obs` pays for one view) and the views alias the allocation."""
+    import torch
+    from bpp_amd.vec_env import StepTensors
+    E, A, M = 5, 8, 8
+    regions = {"obs": (0, torch.float32, (E, 4 * A), E * 4 * A * 4), "mask": (1024, torch.float32, (E, M), E * M * 4),
+               "reward": (2048, torch.float32, (E, 1), E * 4), "done": (2048 + 24, torch.uint8, (E,), E),
+               "_small": (2048, torch.uint8, (64,), 64)}
+    flat = torch.zeros(4096, dtype=torch.uint8)
+    r = StepTensors(_flat=flat, _layout=regions, _offs={"reward": 0, "done": 24}, _hot=32)
+    made = lambda: [k for k in StepTensors.FIELDS if k in [n for n in StepTensors.__slots__ if _has(r, n)]]
+
+    def _has(obj, name):
+        try:
+            object.__getattribute__(obj, name)
+            return True
+        except AttributeError:
+            return False
+
+    assert made() == []
+    assert tuple(r.obs.shape) == (E, 4 * A) and r.obs.dtype == torch.float32 and made() == ["obs"]
+    r.obs[2, 3] = 7.0
+    assert flat[(2 * 4 * A + 3) * 4:(2 * 4 * A + 3) * 4 + 4].view(torch.float32).item() == 7.0      # aliases the allocation
+    assert r["mask"] is r.mask and tuple(r.reward.shape) == (E, 1) and r.done.dtype == torch.uint8
+    assert r.counter is None and r.ratio is None                 # not part of this layout
+    assert float(r.masks.sum()) == E and tuple(r.bad_masks.shape) == (E, 1)
+    with pytest.raises(AttributeError):
+        r.nonsense
+    # built from ready tensors (tests, emulator front-end): plain attributes
+    t = StepTensors(obs=torch.ones(2, 4), done=torch.zeros(2, dtype=torch.uint8))
+    assert t.mask is None and float(t.obs.sum()) == 8.0 and t._flat is None

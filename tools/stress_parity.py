@@ -56,6 +56,8 @@ for trial in range(args.trials):
         assert np.array_equal(getattr(r, k).cpu().numpy(), o[k]), (trial, size, rot, E, k, knobs)
     assert np.array_equal(r.reward.cpu().numpy()[:, 0], o["reward"])
     assert np.array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    assert np.array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc), (trial, "per-bin episode accumulators")
+    assert np.array_equal(env.episode_stats().cpu().numpy(), ref.episode_stats()), (trial, "episode statistics")
     st = env.state_numpy()
     for f in st.dtype.names:
         if f != "pad":
