@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 9
+#define BPP_ABI_VERSION 10
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -160,6 +160,10 @@ typedef struct bpp_step_out {
                           benchmark/soak driver).  May alias the `actions` argument.               */
     uint64_t sample_seed;
     uint64_t sample_step;
+    float   *host_reward; /* NULL, or [E] in page-locked HOST memory mapped into the device (hipHostMalloc; PyTorch's pinned   */
+    uint8_t *host_done;   /* memory): bpp_step ALSO writes reward / done there, so that the host side of VecEnv.step_wait()   */
+                          /* (acktr/envs.py:189-193: CPU reward tensor, numpy done) needs no copy, only bpp_wait(stream).     */
+                          /* Both or neither.                                                                                  */
 } bpp_step_out;
 
 /* Launch-shape tuning knobs of the step/reset/mask kernels (no reference counterpart).  Process-global;
@@ -285,6 +289,9 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
  * hipMemcpyAsync + hipStreamSynchronize in one call.  BppVecEnv.step() fetches reward + done (5 bytes per bin) with
  * it.  The only entry point that blocks the calling thread. */
 int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, void *stream);
+/* hipStreamSynchronize(stream): what step_wait() needs when bpp_step wrote reward / done into host memory itself
+ * (bpp_step_out.host_reward / host_done). */
+int bpp_wait(void *stream);
 
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }

@@ -17,7 +17,7 @@ LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 REDUCE_LANES = 1024
@@ -25,7 +25,7 @@ REDUCE_LANES = 1024
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait"]
 
 
 class Batch(ctypes.Structure):
@@ -53,7 +53,8 @@ class StepOut(ctypes.Structure):
     """struct bpp_step_out"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len",
                                                "next_action")] + [("sample_seed", ctypes.c_uint64),
-                                                                  ("sample_step", ctypes.c_uint64)]
+                                                                  ("sample_step", ctypes.c_uint64),
+                                                                  ("host_reward", ctypes.c_void_p), ("host_done", ctypes.c_void_p)]
 
 
 class Knobs(ctypes.Structure):
@@ -135,6 +136,7 @@ def lib():
         L.bpp_gen_rs.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 5 + [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64,
                                                                           ctypes.c_int32]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_wait.argtypes = [ctypes.c_void_p]
         L.bpp_fetch_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_stream_sizes.argtypes = [ctypes.POINTER(Stream), ctypes.POINTER(ctypes.c_int64)]

@@ -106,6 +106,8 @@ struct Params {
     float *mask;
     float *reward;
     uint8_t *done;
+    float *host_reward;   // mirrors of reward / done in mapped host memory, or nullptr
+    uint8_t *host_done;
     int32_t *counter;
     double *ratio;
     double *ep_ret;
@@ -349,6 +351,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.ep_len += noop ? 0 : 1;
             p.reward[e] = (float)rew;     // acktr/envs.py:192
             p.done[e] = (ok || noop) ? 0 : 1;
+            if (p.host_reward) {
+                p.host_reward[e] = (float)rew;
+                p.host_done[e] = (ok || noop) ? 0 : 1;
+            }
             p.counter[e] = st.n_boxes;    // bin3D.py:111,124
             p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
             p.ep_ret[e] = st.ep_ret;
@@ -915,6 +921,10 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             if (active) {
                 p.reward[e] = (float)rew;                              // acktr/envs.py:192
                 p.done[e] = (ok || noop) ? 0 : 1;
+                if (p.host_reward) {
+                    p.host_reward[e] = (float)rew;
+                    p.host_done[e] = (ok || noop) ? 0 : 1;
+                }
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
                 p.ratio[e] = ratio;
                 p.ep_ret[e] = st.ep_ret;
@@ -1972,6 +1982,8 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     if (!out || !out->obs) return fail(BPP_E_BADARG, "bpp_step_out: NULL obs");
     if (need_all && (!out->reward || !out->done || !out->counter || !out->ratio || !out->ep_ret || !out->ep_len))
         return fail(BPP_E_BADARG, "bpp_step_out: NULL pointer");
+    if ((out->host_reward == nullptr) != (out->host_done == nullptr))
+        return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
     if (((uintptr_t)b->hmap & 3u) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
         ((uintptr_t)b->seq_pool & 3u))
         return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
@@ -1998,6 +2010,8 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.mask = out->mask;
     p.reward = out->reward;
     p.done = out->done;
+    p.host_reward = out->host_reward;
+    p.host_done = out->host_done;
     p.counter = out->counter;
     p.ratio = out->ratio;
     p.ep_ret = out->ep_ret;
@@ -2313,6 +2327,11 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
     hipError_t e = hipMemcpyAsync(host_dst, device_src, (size_t)nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
     e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
+}
+
+int bpp_wait(void *stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
 }
 

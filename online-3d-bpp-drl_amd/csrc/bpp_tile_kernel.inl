@@ -454,6 +454,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
 #endif
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
+        if (p.host_reward) {        // mirrors in mapped host memory: step_wait() then only waits for the stream
+            p.host_reward[e] = out_rew;
+            p.host_done[e] = out_ok ? 0 : 1;
+        }
         p.counter[e] = out_boxes;
         p.ratio[e] = fin_ratio;
         p.ep_ret[e] = fin_ret;

@@ -435,11 +435,12 @@ class BppVecEnv(object):
         self._tstart = time.time()
         return bufs["obs"]
 
-    def step_tensors(self, actions, sample=None):
+    def step_tensors(self, actions, sample=None, _host=None):
         """Enqueue one lock-step; returns device tensors, never synchronises.  actions: int64 [E] or [E,1].
         sample=(seed, step, out): additionally draw, inside the step kernel, the uniform-feasible action
         for the NEW observation into int64 tensor `out` [E] (== sample_feasible(seed, step) on the new mask;
-        `out` may be the action tensor itself)."""
+        `out` may be the action tensor itself).  (_host: page-locked numpy byte buffer the kernel mirrors reward and
+        done into -- step_async's business.)"""
         if self._first_reset:
             raise RuntimeError("call reset() before step()")
         a = actions
@@ -461,6 +462,11 @@ class BppVecEnv(object):
                 raise ValueError("sample out tensor must be a contiguous int64 [E] tensor on the env's device")
             out = _lib.StepOut.from_buffer_copy(self._out)
             out.next_action, out.sample_seed, out.sample_step = nxt.data_ptr(), int(seed), int(step)
+        if _host is not None:
+            if out is self._out:
+                out = _lib.StepOut.from_buffer_copy(self._out)
+            offs, base = self._layout()[2], _host.ctypes.data
+            out.host_reward, out.host_done = base + offs["reward"], base + offs["done"]
         self._last_stream = sp = self._stream_ptr()
         rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
         if rc:
@@ -526,15 +532,22 @@ class BppVecEnv(object):
         return self._res
 
     def step_async(self, actions):
-        self._pending = self.step_tensors(actions)
+        """The reference-shaped path: the step kernel also writes reward and done (5 bytes per bin) straight into a
+        page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing."""
+        host = self._staging()
+        self._pending = (self.step_tensors(actions, _host=host), host)
 
     def step_wait(self):
         """(obs, reward, done, infos) with the reference's types (acktr/envs.py:189-193)."""
-        r, self._pending = self._pending, None
-        if r is None:
+        if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
-        rew, done = r.host_reward_done(self._last_stream)   # ONE device->host copy: 5 bytes per bin
-        done = done.view(np.bool_)                  # the kernels write exactly 0 / 1
+        (r, host), self._pending = self._pending, None
+        rc = self.lib.bpp_wait(self._last_stream)   # the kernel wrote reward / done into `host` itself
+        if rc:
+            _lib.check(rc)
+        offs, E = self._layout()[2], self.E
+        rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
+        done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
 

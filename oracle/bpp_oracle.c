@@ -249,6 +249,8 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
     if (!actions || !out || !out->obs || !out->reward || !out->done || !out->counter || !out->ratio ||
         !out->ep_ret || !out->ep_len)
         return fail(BPP_E_BADARG, "bpp_step: NULL pointer");
+    if ((out->host_reward == NULL) != (out->host_done == NULL))
+        return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
     const int W = b->W, L = b->L, H = b->H, A = W * L;
     for (int e = 0; e < b->num_envs; ++e) {
         bpp_env_state *s = b->state + e;
@@ -264,6 +266,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
             out->ep_len[e] = s->ep_len;
             out->reward[e] = 0.0f;
             out->done[e] = 0;
+            if (out->host_reward) out->host_reward[e] = 0.0f, out->host_done[e] = 0;
             write_obs_mask(b, e, item, out);
             continue;
         }
@@ -320,6 +323,7 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         out->ep_len[e] = s->ep_len;
         out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
         out->done[e] = (uint8_t)done;
+        if (out->host_reward) out->host_reward[e] = (float)reward, out->host_done[e] = (uint8_t)done;
         if (done && b->ep_acc) {                        /* main.py:159-162: the bin's own accumulator row */
             double *a = b->ep_acc + 4 * (size_t)e;
             a[0] += s->ep_ret;
@@ -465,6 +469,11 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
     (void)stream;
     if (!device_src || !host_dst || nbytes <= 0) return fail(BPP_E_BADARG, "bpp_fetch_to_host: NULL pointer / non-positive size");
     memmove(host_dst, device_src, (size_t)nbytes);      /* host pointers on both sides here */
+    return 0;
+}
+
+int bpp_wait(void *stream) {
+    (void)stream;
     return 0;
 }
 

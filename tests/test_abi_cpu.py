@@ -38,14 +38,14 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_limits(lib):
-    assert lib.bpp_abi_version() == 9
+    assert lib.bpp_abi_version() == 10
     assert _lib.limits() == (1024, 255)
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Batch) == 8 * 4 + 2 * 8 + 4 * 8 + 8
     assert _lib.Batch.env_id_base.offset == 32 and _lib.Batch.seq_pool.offset == 48
-    assert ctypes.sizeof(_lib.StepOut) == 64 + 24
+    assert ctypes.sizeof(_lib.StepOut) == 64 + 24 + 16
     from oracle import oracle as orc
     assert ctypes.sizeof(orc.Batch) == ctypes.sizeof(_lib.Batch) and orc.STATE_DTYPE.itemsize == 48
 

@@ -216,3 +216,31 @@ def test_emulated_kernel_selection(emu):
     emu.set_knobs(force_generic=1)
     assert emu.launch_info(65536, (10, 10, 10))[0] == 0
     emu.set_knobs()
+
+
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), True, 70), ((20, 20, 20), False, 9), ((7, 13, 8), False, 19), ((6, 6, 6), True, 37)])
+def test_emulated_step_mirrors_reward_and_done_into_host_buffers(emu, oracle, variant, size, rot, E):
+    """bpp_step_out.host_reward / host_done (ABI v10): the step kernels write reward and done a second time, into the
+    buffers step_wait() reads without a copy -- all three kernels, NOOP bins included."""
+    import ctypes
+    from bpp_amd import sequences
+    pool = sequences.cut2_pool(size, 8, seed=6, bound=(2, min(5, min(size) // 2)), native=False)
+    for mod in (emu, oracle):
+        env = mod.OracleEnv(pool, size, rot, E)
+        _, mask = env.reset()
+        hr, hd = np.full(E, -1.0, np.float32), np.full(E, 7, np.uint8)
+        env._o.host_reward, env._o.host_done = hr.ctypes.data, hd.ctypes.data
+        rng = np.random.RandomState(2)
+        for t in range(12):
+            a = oracle.sample_feasible(mask, 4, t)
+            a[rng.rand(E) < 0.2] = -1
+            a[rng.rand(E) < 0.2] = -2 ** 63                  # BPP_ACTION_NOOP
+            o = env.step(a)
+            np.testing.assert_array_equal(hr, o["reward"])
+            np.testing.assert_array_equal(hd, o["done"])
+            mask = o["mask"]
+        env._o.host_done = None                              # one without the other is refused
+        with pytest.raises(RuntimeError):
+            env.step(a)
+        env._o.host_reward = None
+        env.step(a)

@@ -54,7 +54,8 @@ def main():
             out["%s%s_us_per_lockstep" % (kind, "_fresh_outputs" if fresh else "")] = round(us, 1)
         del env
         torch.cuda.empty_cache()
-    out["note"] = ("step = step kernel + separate action-sampling launch + one 5-byte-per-bin device->host copy + stream sync; "
+    out["note"] = ("step = step kernel (also writing reward + done, 5 bytes per bin, into page-locked host memory) + separate "
+                   "action-sampling launch + stream sync; "
                    "+finished_infos: gather and copy the finished bins' (r, l, ratio, counter); +running_info: copy counter / ratio "
                    "of all bins (12 bytes per bin)")
     print(json.dumps(out))
