@@ -317,6 +317,7 @@ class BppVecEnv(object):
         self._out = None
         self._res = None
         self._first_reset = True
+        self._out_pool = []        # fresh_outputs: output sets that may be handed out again once unreferenced
         self._last_stream = None
         self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
@@ -356,15 +357,34 @@ class BppVecEnv(object):
         return lay
 
     def _alloc(self):
+        """One set of output buffers: (StepTensors over one flat allocation, bpp_step_out with its pointers).  With
+        fresh_outputs=True every step gets its own set; sets whose storage nobody references any more (the StepTensors
+        AND every view made from it are gone -- torch's storage use count says so) are handed out again instead of going
+        through the allocator: same lifetime rule as the caching allocator's (the next writer is a kernel on the caller's
+        stream, ordered behind whatever was enqueued there before)."""
         regions, total, offs, hot = self._layout()
-        flat = torch.empty((total,), dtype=torch.uint8, device=self.device)
-        base = flat.data_ptr()
+        use_count = getattr(torch._C, "_storage_Use_Count", None) if self.fresh_outputs else None
+        flat = out = None
+        if use_count is not None:
+            pool = self._out_pool
+            for k, (f, o) in enumerate(pool):
+                if use_count(f.untyped_storage()._cdata) <= 2:      # the pool's tensor + the wrapper just made for the query
+                    flat, out = f, o
+                    pool.append(pool.pop(k))
+                    break
+        if flat is None:
+            flat = torch.empty((total,), dtype=torch.uint8, device=self.device)
+            base = flat.data_ptr()
+            ptr_offs = getattr(self, "_ptr_offs", None)
+            if ptr_offs is None:
+                ptr_offs = self._ptr_offs = [(regions[k][0] if k in regions else None)
+                                             for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
+            out = _lib.StepOut(*[(base + o if o is not None else None) for o in ptr_offs])
+            if use_count is not None and len(self._out_pool) < 8:
+                self._out_pool.append((flat, out))
+        if use_count is not None:
+            flat = flat.detach()        # the result's own handle on the storage: the pool's stays the only one when it is gone
         res = StepTensors(_flat=flat, _layout=regions, _offs=offs, _stage=self._staging, _hot=hot)
-        ptr_offs = getattr(self, "_ptr_offs", None)
-        if ptr_offs is None:
-            ptr_offs = self._ptr_offs = [(regions[k][0] if k in regions else None)
-                                         for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len")]
-        out = _lib.StepOut(*[(base + o if o is not None else None) for o in ptr_offs])
         return res, out
 
     def _staging(self):
