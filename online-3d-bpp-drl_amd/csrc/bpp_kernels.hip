@@ -1730,7 +1730,30 @@ __global__ __launch_bounds__(BPP_REDUCE_LANES) void stats_kernel(const uint8_t *
 // The same from the per-bin accumulator rows bpp_step keeps (bpp_batch.ep_acc).
 __global__ __launch_bounds__(BPP_REDUCE_LANES) void acc_reduce_kernel(double *ep_acc, int E, double *acc, int clear) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int e = threadIdx.x; e < E; e += BPP_REDUCE_LANES) {
+    // rows threadIdx.x, + 1024, + 2048, ... added in that order; eight rows are in flight at a time (the loads are
+    // independent, only the additions are ordered)
+    constexpr int U = 8;
+    int e = threadIdx.x;
+    for (; e + (U - 1) * BPP_REDUCE_LANES < E; e += U * BPP_REDUCE_LANES) {
+        double v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double *a = (const double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
+            v[u][0] = a[0], v[u][1] = a[1], v[u][2] = a[2], v[u][3] = a[3];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s0 = s0 + v[u][0];
+            s1 = s1 + v[u][1];
+            s2 = s2 + v[u][2];
+            s3 = s3 + v[u][3];
+            if (clear) {
+                double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
+                a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
+            }
+        }
+    }
+    for (; e < E; e += BPP_REDUCE_LANES) {
         double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
         const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
         s0 = s0 + v0;
