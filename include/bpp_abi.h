@@ -212,7 +212,9 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
  * rotation quirk (bin3D.py:96-105), placement rule (space.py:111-144), heightmap update
  * (space.py:36-46,164-181), reward (bin3D.py:44-46,114-121), info (bin3D.py:111,123-125), Monitor
  * (baselines/bench/monitor.py:51-77), auto-reset (shmem_vec_env.py:126-130), next observation
- * (bin3D.py:61-66) and its feasibility mask (acktr/utils.py:37-94).  actions: [E] int64. */
+ * (bin3D.py:61-66) and its feasibility mask (acktr/utils.py:37-94); finished episodes are added to the bins' rows of
+ * bpp_batch.ep_acc (main.py:159-162); with out->host_reward / host_done set, reward and done are ALSO written into that
+ * mapped host memory (acktr/envs.py:189-193 hands the loop a CPU reward tensor and a numpy done).  actions: [E] int64. */
 int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *stream);
 
 /* Batched drop-in for acktr.utils.get_possible_position (rotation=0, acktr/utils.py:37-62) and

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "bpp_kernels.hip")
 # build() only ever writes BUILD_LIB.  BPP_HIP_LIB: LOAD another build of the same library instead (profiling /
-# diagnostic builds of tools/build_ablation.sh, tools/stress_stats.py) -- never built to, never a fallback
+# diagnostic builds of tools/build_variant.sh abl -DBPP_ENABLE_ABLATION, tools/stress_stats.py) -- never built to, never a fallback
 BUILD_LIB = os.path.join(CSRC, "libbpp_hip.so")
 LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")

@@ -38,7 +38,7 @@
 
 #pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
 
-// Profiling aid, compiled in only with -DBPP_ENABLE_ABLATION (tools/build_ablation.sh): BPP_ABLATE=<bit mask>
+// Profiling aid, compiled in only with -DBPP_ENABLE_ABLATION (tools/build_variant.sh abl -DBPP_ENABLE_ABLATION): BPP_ABLATE=<bit mask>
 // then skips individual phases so their cost can be read off rocprofv3 (results are wrong when used).
 #ifdef BPP_ENABLE_ABLATION
 #define BPP_ABL(p, bit) (((p).ablate & (bit)) != 0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock timeline of bpp_tile_kernel inside a full-size launch (profiling build only).
 
-    tools/build_ablation.sh && BPP_HIP_LIB=online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so python tools/phase_timeline.py [--groups N]
+    tools/build_variant.sh abl -DBPP_ENABLE_ABLATION && BPP_HIP_LIB=online-3d-bpp-drl_amd/csrc/libbpp_hip_abl.so python tools/phase_timeline.py [--groups N]
 
 Lane 0 of every wave of every 8th workgroup stamps s_memtime at the phase boundaries of ONE launch; printed: median
 cycles between consecutive stamps, for the deciding wave (wave 0) and the other waves, plus wave lifetime."""
@@ -30,7 +30,7 @@ def main():
     import bpp_amd
     lib = bpp_amd._lib.lib()
     if not hasattr(lib, "bpp_debug_stamps"):
-        raise SystemExit("needs the profiling build: tools/build_ablation.sh, then BPP_HIP_LIB=.../libbpp_hip_abl.so")
+        raise SystemExit("needs the profiling build: tools/build_variant.sh abl -DBPP_ENABLE_ABLATION, then BPP_HIP_LIB=.../libbpp_hip_abl.so")
     size = tuple(args.size)
     pool = bpp_amd.sequences.cut2_pool(size, 2048, seed=0)
     bpp_amd._lib.set_knobs(tile_groups=args.groups)
