@@ -42,9 +42,6 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 #ifndef BPP_TILE_LDS_PAD
 #define BPP_TILE_LDS_PAD 0
 #endif
-#ifndef BPP_TILE_LATE_POOL
-#define BPP_TILE_LATE_POOL 0   // 1: next-step pool entries loaded behind the second barrier (measured: 28.3 -> 28.9 us, stream mode 55.1 -> 57.6 us/lock-step)
-#endif
 #ifndef BPP_EXP_FORCE_LOW
 #define BPP_EXP_FORCE_LOW 0    // 1: TIMING EXPERIMENT ONLY (wrong masks for tall bins): 20x20 always on the one-word path, LDS sized for it
 #endif
@@ -228,8 +225,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     float out_rew = 0.0f;
     int fin_len = 0, out_boxes = 0;
     bpp_env_state st_out;
-    size_t late_a = 0, late_b = 0;
-    int late_kind = 0;
     if (kDecide && wid == 0 && !BPP_ABL(p, 32)) {
         __builtin_amdgcn_s_setprio(3);                 // the other waves of the workgroup wait for this chain
         const bool lead = dactive && ql == 0;          // the lane that writes the bin's results
@@ -253,18 +248,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             int seq_nn = seq_n + p.seq_stride;
             seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
             const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-#if BPP_TILE_LATE_POOL
-            // The pool entries the NEXT step needs only go into the state record, never into this step's outputs: their
-            // loads are issued behind the second barrier, and only those of the branch taken (a barrier waits for a
-            // wave's outstanding loads -- with a ring pool these are HBM misses, and all four waves waited for them).
-            const size_t pl_ok = (size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1);
-            const size_t pl_f1 = (size_t)seq_n * Tn + min(1, Tn - 1), pl_f2 = (size_t)seq_nn * Tn;
-            const uint32_t sp_ok = 0u, sp_f1 = 0u, sp_f2 = 0u;
-#else
             const uint32_t sp_ok = p.pool[(size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1)];
             const uint32_t sp_f1 = p.pool[(size_t)seq_n * Tn + min(1, Tn - 1)];
             const uint32_t sp_f2 = p.pool[(size_t)seq_nn * Tn];
-#endif
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
@@ -367,12 +353,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 r.item = it_rst;
                 r.flags = 2u | 4u;
             }
-#if BPP_TILE_LATE_POOL
-            late_a = ok ? pl_ok : pl_f1;               // -> item_next (either way); unused for a bin left alone
-            late_b = pl_f2;                            // -> item_reset after a failed placement
-            late_kind = noop ? 0 : (ok ? 1 : 2);
-#endif
-            st_out = st;   // written behind the second barrier
+            // written behind the second barrier.  (Loading the look-ahead pool entries there as well -- they only go into this
+            // record -- instead of speculatively before the decision was measured twice, state store right after the loads
+            // and state tail stored at the end of the kernel: 28.3 -> 28.9 / 29.2 us, stream mode 52.4 -> 55.3 us per lock-step.)
+            st_out = st;
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -447,11 +431,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)e, 32);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
-#if BPP_TILE_LATE_POOL
-        uint32_t la = 0u, lb = 0u;
-        if (late_kind != 0) la = p.pool[late_a];
-        if (late_kind == 2) lb = p.pool[late_b];
-#endif
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
         if (p.host_reward) {        // mirrors in mapped host memory: step_wait() then only waits for the stream
@@ -462,10 +441,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         p.ratio[e] = fin_ratio;
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
-#if BPP_TILE_LATE_POOL
-        if (late_kind != 0) st_out.item_next = la;
-        if (late_kind == 2) st_out.item_reset = lb;
-#endif
         p.state[e] = st_out;
         if (acc) {
             ea[0] = a0 + fin_ret;
