@@ -263,6 +263,31 @@ def test_gpu_native_rollout_driver_matches_oracle(bpp, oracle):
         np.testing.assert_array_equal(env.state_numpy()["episode"], ref.state["episode"])
 
 
+@pytest.mark.parametrize("size,rot,E,steps", [((20, 20, 20), False, 4096, 150), ((20, 20, 20), True, 1024, 110), ((20, 20, 22), False, 1024, 110)])
+def test_gpu_tall_20x20_bins_two_phase_scan_matches_oracle(bpp, oracle, size, rot, E, steps):
+    """The 20x20 kernel holds a ONE-word prefix image: a bin taller than 11 is scanned in two phases (upper word, then
+    lower word).  Long rollouts so that a large share of the bins is tall at the end, every lock-step's final state and
+    outputs compared with the oracle; the share of tall bins is asserted so that the path cannot go untested."""
+    pool = bpp.sequences.cut2_pool(size, 64, seed=13)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool)
+    ref = oracle.OracleEnv(pool, size, rot, E)
+    env.reset(), ref.reset()
+    tall_seen, done_steps = 0, 0
+    for chunk in (steps // 3, steps // 3, steps - 2 * (steps // 3)):
+        r = env.rollout_uniform(seed=17, step0=done_steps, nsteps=chunk)
+        o, _ = oracle.rollout_uniform(ref, 17, done_steps, chunk)
+        done_steps += chunk
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), o[k], err_msg="%s after %d" % (k, done_steps))
+        np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+        st = env.state_numpy()
+        np.testing.assert_array_equal(st["hmax"], ref.state["hmax"])
+        np.testing.assert_array_equal(st["hmax"], ref.hmap.max(1))          # the record's hmax IS the map's maximum
+        tall_seen = max(tall_seen, int((st["hmax"] > 11).sum()))
+    np.testing.assert_array_equal(env.episode_stats().cpu().numpy(), ref.episode_stats())
+    assert tall_seen > E // 20, tall_seen
+
+
 def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
     """The reference-shaped entry point: make_vec_envs(...) -> step() -> (obs device f32, reward CPU f32
     [N,1], done numpy bool, infos of dicts) exactly like VecPyTorch (acktr/envs.py:170-193), replayed
