@@ -42,6 +42,16 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 #ifndef BPP_TILE_LDS_PAD
 #define BPP_TILE_LDS_PAD 0
 #endif
+// Where a finishing bin's episode-accumulator row is read and written back (measured, one output set / outputs past the
+// Infinity Cache; 10x10: 28.4 / 32.8 us, + rotation 35.1 / 38.6 us, 20x20 57.6 / 57.6 us with mode 0):
+//   0  read behind the second barrier, added and stored at once -- a DRAM latency on the deciding wave's path once the
+//      accumulators no longer stay in the Infinity Cache;
+//   1  read up front with the state record by EVERY bin (28.8 / 31.4, 35.4 / 36.4, 58.3 / 58.4 us);
+//   2  read behind the second barrier, added and stored at the END of the kernel (28.5 / 30.8, 34.9 / 36.2, 58.4 / 60.1 us).
+// -> mode 2 where a wave owns several bins, mode 0 for the 20x20 bin.  BPP_TILE_ACC_MODE overrides (experiments).
+#ifndef BPP_TILE_ACC_MODE
+#define BPP_TILE_ACC_MODE (-1)
+#endif
 #ifndef BPP_EXP_FORCE_LOW
 #define BPP_EXP_FORCE_LOW 0    // 1: TIMING EXPERIMENT ONLY (wrong masks for tall bins): 20x20 always on the one-word path, LDS sized for it
 #endif
@@ -130,6 +140,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     constexpr int A = T::A, A4 = T::A4, M = T::M, M4 = T::M4, PW = T::PW, PN = T::PN, G = T::G, NB = T::NB, LPB = T::LPB;
     constexpr int NPASS = T::NPASS, NBW = T::NBW;
     constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
+    constexpr int kAccMode = BPP_TILE_ACC_MODE >= 0 ? BPP_TILE_ACC_MODE : (EPW > 1 ? 2 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,9 +168,17 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     const int dec_e = blk_e0 + (dactive ? db : 0);
     bpp_env_state st0;
     int64_t act0 = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    bool acc_late = false;
     if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
         st0 = p.state[dec_e];
         act0 = p.actions[dec_e];
+        if constexpr (kAccMode == 1) {   // the row of EVERY bin, read with the state record
+            if (p.ep_acc != nullptr && !BPP_ABL(p, 128)) {
+                const double *ea0 = (const double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
+                acc0 = ea0[0], acc1 = ea0[1], acc2 = ea0[2], acc3 = ea0[3];
+            }
+        }
     }
 
     // ---- phase 1: stage the byte tiles of ALL the wave's bins (lane owns quads sl + G*k of bin it*EPW + el) ----
@@ -429,8 +448,13 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         // latency overlaps the stores below
         const bool acc = p.ep_acc != nullptr && fin && !BPP_ABL(p, 128);
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)e, 32);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
+        double a0 = acc0, a1 = acc1, a2 = acc2, a3 = acc3;
+        if constexpr (kAccMode == 0) {
+            if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
+        } else if constexpr (kAccMode == 2) {
+            if (acc) acc0 = ea[0], acc1 = ea[1], acc2 = ea[2], acc3 = ea[3];   // consumed at the end of the kernel
+            acc_late = acc;
+        }
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
         if (p.host_reward) {        // mirrors in mapped host memory: step_wait() then only waits for the stream
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
         p.state[e] = st_out;
-        if (acc) {
+        if (kAccMode != 2 && acc) {
             ea[0] = a0 + fin_ret;
             ea[1] = a1 + fin_ratio;
             ea[2] = a2 + (double)fin_len;
@@ -851,5 +875,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 }
         }
         if (it == NIT - 1) BPP_STAMP(p, 10);
+    }
+    if (kAccMode == 2 && MODE == kStep && wid == 0 && acc_late) {   // the row read behind the second barrier has long arrived
+        double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
+        ea[0] = acc0 + fin_ret;
+        ea[1] = acc1 + fin_ratio;
+        ea[2] = acc2 + (double)fin_len;
+        ea[3] = acc3 + 1.0;
     }
 }
