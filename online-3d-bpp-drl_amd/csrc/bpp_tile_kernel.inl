@@ -42,13 +42,18 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 #ifndef BPP_TILE_LDS_PAD
 #define BPP_TILE_LDS_PAD 0
 #endif
-// Where a finishing bin's episode-accumulator row is read and written back (measured, one output set / outputs past the
-// Infinity Cache; 10x10: 28.4 / 32.8 us, + rotation 35.1 / 38.6 us, 20x20 57.6 / 57.6 us with mode 0):
-//   0  read behind the second barrier, added and stored at once -- a DRAM latency on the deciding wave's path once the
-//      accumulators no longer stay in the Infinity Cache;
-//   1  read up front with the state record by EVERY bin (28.8 / 31.4, 35.4 / 36.4, 58.3 / 58.4 us);
-//   2  read behind the second barrier, added and stored at the END of the kernel (28.5 / 30.8, 34.9 / 36.2, 58.4 / 60.1 us).
-// -> mode 2 where a wave owns several bins, mode 0 for the 20x20 bin.  BPP_TILE_ACC_MODE overrides (experiments).
+// Where a finishing bin's episode-accumulator row is read and written back.  Measured on one box, 10x10 / + rotation,
+// one output set | outputs rotated past the Infinity Cache (profiles/r3x_ab_r3aa.txt):
+//   0  read behind the second barrier, added and stored at once: 28.37 | 33.08, 34.61 | 39.17 us -- past the Infinity
+//      Cache the 2 MB of rows are DRAM reads, a latency on the deciding wave's path;
+//   1  read up front with the state record by EVERY bin, values kept: 28.76 | 31.36, 35.10 | 36.38 us (eight more live
+//      registers through the decision);
+//   3  read up front by every bin AS A PREFETCH (the values are dead unless the bin finishes), read again behind the
+//      second barrier by the finishing bins -- now a cache hit --, added and stored at the END of the kernel:
+//      28.46 | 30.59, 34.75 | 36.19 us;
+//   4  like 1, stored at the end: 28.81 | 31.27 us;  2  like 0, stored at the end: no better than 0.
+// -> mode 3 where a wave owns several bins; the 20x20 kernel (one bin per wave, already at its memory floor past the
+// Infinity Cache) keeps mode 0 (mode 3 there: 57.6 -> 58.4 | 57.6 -> 60.1 us).  BPP_TILE_ACC_MODE overrides (experiments).
 #ifndef BPP_TILE_ACC_MODE
 #define BPP_TILE_ACC_MODE (-1)
 #endif
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     constexpr int A = T::A, A4 = T::A4, M = T::M, M4 = T::M4, PW = T::PW, PN = T::PN, G = T::G, NB = T::NB, LPB = T::LPB;
     constexpr int NPASS = T::NPASS, NBW = T::NBW;
     constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
-    constexpr int kAccMode = BPP_TILE_ACC_MODE >= 0 ? BPP_TILE_ACC_MODE : (EPW > 1 ? 2 : 0);
+    constexpr int kAccMode = BPP_TILE_ACC_MODE >= 0 ? BPP_TILE_ACC_MODE : (EPW > 1 ? 3 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
         st0 = p.state[dec_e];
         act0 = p.actions[dec_e];
-        if constexpr (kAccMode == 1) {   // the row of EVERY bin, read with the state record
+        if constexpr (kAccMode == 1 || kAccMode == 3 || kAccMode == 4) {   // the row of EVERY bin, read with the state record
             if (p.ep_acc != nullptr && !BPP_ABL(p, 128)) {
                 const double *ea0 = (const double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
                 acc0 = ea0[0], acc1 = ea0[1], acc2 = ea0[2], acc3 = ea0[3];
@@ -451,8 +456,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         double a0 = acc0, a1 = acc1, a2 = acc2, a3 = acc3;
         if constexpr (kAccMode == 0) {
             if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
-        } else if constexpr (kAccMode == 2) {
+        } else if constexpr (kAccMode == 2 || kAccMode == 3) {
             if (acc) acc0 = ea[0], acc1 = ea[1], acc2 = ea[2], acc3 = ea[3];   // consumed at the end of the kernel
+            acc_late = acc;
+        } else if constexpr (kAccMode == 4) {
             acc_late = acc;
         }
         p.reward[e] = out_rew;
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
         p.state[e] = st_out;
-        if (kAccMode != 2 && acc) {
+        if (kAccMode <= 1 && acc) {
             ea[0] = a0 + fin_ret;
             ea[1] = a1 + fin_ratio;
             ea[2] = a2 + (double)fin_len;
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
         if (it == NIT - 1) BPP_STAMP(p, 10);
     }
-    if (kAccMode == 2 && MODE == kStep && wid == 0 && acc_late) {   // the row read behind the second barrier has long arrived
+    if (kAccMode >= 2 && MODE == kStep && wid == 0 && acc_late) {   // the row read behind the second barrier has long arrived
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
         ea[0] = acc0 + fin_ret;
         ea[1] = acc1 + fin_ratio;
