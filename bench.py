@@ -329,11 +329,11 @@ def main():
 
     def timed_region(sets=None, log=True):
         fence()
-        # HIP events around the launches of every 8th region (and the first three): recording a pair costs ~10 us of
+        # HIP events around the launches of every 8th region (and regions 2-4): recording a pair costs ~10 us of
         # host time, which a region of 20 lock-steps would feel
         kind = "past_l3" if sets is not None and sets is not only_sets else "headline"
         region_count[kind] = region_count.get(kind, 0) + 1
-        sampled = region_count[kind] <= 3 or region_count[kind] % 8 == 0
+        sampled = 2 <= region_count[kind] <= 4 or region_count[kind] % 8 == 0      # (a leg's first region runs cold)
         if sampled:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
