@@ -14,8 +14,9 @@ actions) are resident in HBM.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job env steps/s, plus
 `roofline` (dominant kernel = bpp_step; algorithmic bytes / HIP-event-measured launch duration vs the
-8 TB/s HBM peak) and `cpu_baseline` (the C oracle, a scalar port of the reference, timed on this box's
-host: 1 core, bounded sample; N=1 only).
+8 TB/s HBM peak) and `cpu_baseline` (the unmodified reference Python from oracle/_ref/ -- its own ShmemVecEnv
+plumbing and one worker per core -- timed on this box's host cores in this run, the C restatement beside it;
+bounded samples; N=1 only).
 """
 import argparse
 import json
@@ -47,8 +48,10 @@ def parse():
     ap.add_argument("--rotation", action="store_true")
     ap.add_argument("--pool", type=int, default=8192, help="CUT-2 sequences in the pool")
     ap.add_argument("--pool-file", default=None,
-                    help="npz with a uint8 [P][T][4] `pool` array instead of generated sequences, e.g. "
-                         "tests/golden/cut2_dataset_10.npz = the reference's dataset/cut_2.pt (2100 sequences)")
+                    help="npz with a uint8 [P][T][4] `pool` array (every row ending in the terminator: (10,10,10) for a 10x10x10 "
+                         "bin, else the bin size) or a reference dataset/*.pt, instead of generated sequences; played in "
+                         "LoadBoxCreator's order (row r = trajectory r + 1), e.g. tests/golden/cut2_dataset_10.npz = the "
+                         "reference's dataset/cut_2.pt (2100 sequences)")
     ap.add_argument("--stream", action="store_true",
                     help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
                          "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
@@ -57,7 +60,10 @@ def parse():
                     help="--stream: lock-steps between refills (with depth >= 2 * refill + 3 the refills run beside the lock-steps)")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed K-step region; the MEDIAN repetition is reported (0 = auto: as many as "
-                         "it takes for >= 200 ms of timed GPU work, so that a small --steps is not a 1 ms sample)")
+                         "it takes for --gpu-seconds of timed GPU work, so that a small --steps is not a 1 ms sample)")
+    ap.add_argument("--gpu-seconds", type=float, default=3.0,
+                    help="timed GPU work of the headline leg (the past-L3 leg gets two thirds of it): long enough for an "
+                         "outside utilisation sampler to see the device busy; the median repetition is what is reported")
     ap.add_argument("--launcher", choices=("auto", "direct", "spawn"), default="auto",
                     help="auto: --gpus N > 1 started without torch.distributed.run launches its N ranks itself; spawn: do "
                          "that for N = 1 as well")
@@ -107,65 +113,91 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(pool, size, rotation, seconds):
-    """The oracle (oracle/bpp_oracle.c: scalar C port of the reference step + mask) on the host, same
-    workload and policy, time-bounded sample: one core alone, then one process per usable core (each with
-    its own shard of bins).  Checker/baseline only -- never the product path."""
+    """The CPU side of the line, timed on THIS box's host cores in THIS run (rank 0, N = 1 only; baselines, not targets):
+
+    * `kind: "reference"` -- the UNMODIFIED reference Python from oracle/_ref/ (byte-for-byte copies made by the
+      committed recipe oracle/make_ref.py; /root/reference is never read here), in a process of its own
+      (oracle/ref_baseline.py): R1 = its ShmemVecEnv plumbing as it is (16 forked workers + the parent's mask loop,
+      BASELINE config[0]); R2 = one forked worker per usable core running PackingGame.step + acktr.utils masks on the
+      bench's own CUT-2 pool and policy.  `value` is R2 (same workload, all cores), R1 is carried beside it.
+    * `ours_cpu` -- oracle/bpp_oracle.c, the scalar C restatement (the parity checker), same pool and policy.
+
+    Without oracle/_ref/ the line falls back to `kind: "port"` (the C restatement as `value`, plus the Python
+    restatement oracle/ref_port.py) and says so."""
     import multiprocessing as mp
     from oracle import oracle as orc
+    from oracle import ref_shims
     orc.build()
-    bins = 256
-    n1, dt1 = _cpu_worker((pool, size, rotation, bins, 0, bins, 0.3 * seconds))
-    single = bins * n1 / dt1
     cores = min(usable_cores(), 64)
-    jobs = [(pool, size, rotation, bins, c * bins, cores * bins, 0.5 * seconds) for c in range(cores)]
+    have_ref = ref_shims.copy_available()
+    c_budget = (0.35 if have_ref else 0.6) * seconds
+    bins = 256
+    n1, dt1 = _cpu_worker((pool, size, rotation, bins, 0, bins, 0.4 * c_budget))
+    single = bins * n1 / dt1
+    jobs = [(pool, size, rotation, bins, c * bins, cores * bins, 0.6 * c_budget) for c in range(cores)]
     with mp.get_context("fork").Pool(cores) as pw:
         res = pw.map(_cpu_worker, jobs)
     rate = sum(bins * n / dt for n, dt in res)     # every worker measured over its own busy interval
-    return {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "reference_subprocvecenv_timed_here": False,
-            "why_not": "north_star's baseline is the reference's own SubprocVecEnv / ShmemVecEnv plumbing (acktr/envs.py:77-118, parent-side "
-                       "mask loop main.py:163-169); the reference tree does not exist on the GPU box, so what is timed in this run is "
-                       "(1) this C port of the same step + mask and (2) `python_port`, a Python / numpy restatement of one reference worker "
-                       "and the parent's mask loop; the unmodified reference's own throughput was measured in the build container only "
-                       "(`reference_python_context`)",
-            "single_core_value": single, "python_port": python_port_baseline(pool, size, rotation, cores, 0.4 * seconds),
-            "reference_python_context": reference_python_context(),
-            "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); "
-                      "%d processes x %d bins for %.1f s each (sum of per-process rates), and %d bins x %d lock-steps "
-                      "in %.1f s on one core; same CUT-2 pool and uniform-feasible policy; os.cpu_count()=%s"
-                      % (cores, bins, 0.5 * seconds, bins, n1, dt1, os.cpu_count())}
+    ours = {"value": rate, "unit": "env steps/s", "cores": cores, "kind": "port", "single_core_value": single,
+            "sample": "oracle/bpp_oracle.c (scalar C restatement of PackingGame.step + acktr.utils mask); %d processes x %d bins "
+                      "for %.1f s each (sum of per-process rates), and %d bins x %d lock-steps in %.1f s on one core; same CUT-2 "
+                      "pool and uniform-feasible policy" % (cores, bins, 0.6 * c_budget, bins, n1, dt1)}
+    if not have_ref:
+        ours.update({"reference_subprocvecenv_timed_here": False,
+                     "why_not": "oracle/_ref/ is missing on this box (made by oracle/make_ref.py in the build container; it travels "
+                                "with the working tree, not with git): the reference's own plumbing could not be timed here",
+                     "python_port": python_port_baseline(pool, size, rotation, cores, 0.4 * seconds)})
+        return ours
+    ref = reference_baseline(pool, size, rotation, cores, 0.3 * seconds, 0.35 * seconds)
+    r1, r2 = ref.get("R1", {}), ref.get("R2", {})
+    if "value" not in r2:       # the reference leg failed: say why, fall back to the port as the value
+        ours.update({"reference_subprocvecenv_timed_here": False, "reference_error": ref})
+        return ours
+    return {"value": r2["value"], "unit": "env steps/s", "cores": cores, "kind": "reference",
+            "reference_subprocvecenv_timed_here": "value" in r1,
+            "sample": "R2: unmodified reference Python (oracle/_ref/), %d forked workers x 1 bin for %.1f s each = %d env steps: "
+                      "PackingGame.step + acktr.utils mask per worker, the bench's CUT-2 pool, uniform-feasible policy.  "
+                      "R1 (reference plumbing as it is) beside it; os.cpu_count()=%s, usable cores %d"
+                      % (cores, r2.get("seconds", 0.0), r2.get("env_steps", 0), os.cpu_count(), cores),
+            "reference_parallel_R2": r2, "reference_as_is_R1": r1, "ours_cpu": ours}
+
+
+def reference_baseline(pool, size, rotation, cores, r1_seconds, r2_seconds):
+    """oracle/ref_baseline.py in its own process (the reference's modules never enter this one; it forks its workers
+    from a process that holds no HIP state)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from oracle import ref_shims
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "pool.npz")
+            np.savez(path, pool=np.asarray(pool))
+            spec = {"pool": path, "size": list(size), "rotation": bool(rotation), "cores": cores,
+                    "r1_seconds": r1_seconds, "r2_seconds": r2_seconds}
+            env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_baseline.py"), ref_shims.REF_COPY, json.dumps(spec)],
+                                 capture_output=True, text=True, env=env, timeout=60 + 4 * (r1_seconds + r2_seconds))
+        for line in out.stdout.splitlines():
+            if line.startswith("REF_BASELINE="):
+                return json.loads(line[len("REF_BASELINE="):])
+        return {"error": "no result line", "stderr_tail": out.stderr[-400:]}
+    except Exception as exc:  # noqa: BLE001 -- a baseline must never take the bench line down
+        return {"error": repr(exc)}
 
 
 def python_port_baseline(pool, size, rotation, cores, seconds):
-    """north_star asks for the reference SubprocVecEnv timed on this box's host cores in this run; the reference tree
-    does not travel to the GPU box, so what is timed here is oracle/ref_port.py: a pure-Python / numpy restatement of one
-    reference worker's step plus the parent's mask loop with the same numpy work per candidate position, one forked
-    process per usable core -- the reference's plumbing with a perfectly parallel mask loop.  Its outputs are pinned to
-    the C oracle (tests/test_ref_port.py); in the build container it runs at 1.02 - 1.10 x the speed of the live
-    reference on the same core (oracle/time_reference.py, profiles/r03o_reference_python_and_port_cpu_here.json)."""
+    """Fallback only (no oracle/_ref/ on the box): oracle/ref_port.py, a pure-Python / numpy restatement of one reference
+    worker's step plus the parent's mask loop, one forked process per usable core.  Its outputs are pinned to the C
+    oracle (tests/test_ref_port.py)."""
     try:
         from oracle import ref_port
         rate, longest = ref_port.timed_all_cores(pool, size, rotation, seconds, cores)
         return {"value": rate, "unit": "env steps/s", "cores": cores, "per_core": rate / cores, "kind": "port (Python)",
                 "sample": "oracle/ref_port.py, %d forked workers x 1 bin for %.1f s each; same CUT-2 pool, "
-                          "uniform-feasible policy" % (cores, longest),
-                "speed_vs_live_reference_same_core": "1.02-1.10x (build container, profiles/r03o_reference_python_and_port_cpu_here.json)"}
+                          "uniform-feasible policy" % (cores, longest)}
     except Exception as e:       # a baseline must never take the bench line down
         return {"error": repr(e)}
-
-
-def reference_python_context():
-    """The UNMODIFIED reference Python cannot run on the GPU box (/root/reference is not shipped there); its
-    host throughput was measured in the build container (oracle/time_reference.py) and is carried here as
-    labelled context next to the C port's number -- not measured in this run, not on this box."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03o_reference_python_and_port_cpu_here.json")))
-        d = dict(d)
-        d["note"] = ("measured in the build container (8 cores), not on this box and not in this run: the reference "
-                     "tree does not travel to the GPU box; profiles/r03o_reference_python_and_port_cpu_here.json")
-        return d
-    except Exception:
-        return None
 
 
 def profile_evidence(key):
@@ -237,7 +269,10 @@ def main():
     M = A * (2 if args.rotation else 1)
     E = args.envs
     if args.pool_file:
-        pool = bpp_amd.sequences.from_dataset(args.pool_file, size)   # .npz ([P][T][4] `pool`) or a reference dataset/*.pt
+        # .npz ([P][T][4] `pool`) or a reference dataset/*.pt, played as the reference's LoadBoxCreator plays it (first
+        # episode = trajectory 1; rows end in the terminator: the reference's literal (10,10,10) for its own 10x10x10
+        # sets, the bin size for any other bin)
+        pool = bpp_amd.sequences.from_dataset(args.pool_file, size, terminator=(10, 10, 10) if size == (10, 10, 10) else size)
     else:
         pool = bpp_amd.sequences.cut2_pool(size, args.pool, seed=0)   # identical on every rank (cpu_baseline uses it too)
     cpu_base = None
@@ -317,7 +352,7 @@ def main():
     stats.collect(env).all_reduce()   # also loads the few torch kernels the collection uses
     stats.zero_()
     # timed region = EXACTLY K lock-steps: barrier + synchronize, clock, K lock-steps, synchronize, clock (the maximum
-    # over ranks is taken afterwards); repeated `reps` times -- as often as it takes for >= 200 ms of timed GPU work,
+    # over ranks is taken afterwards); repeated `reps` times -- as often as it takes for --gpu-seconds (default 3 s) of timed GPU work,
     # whatever K is -- and the MEDIAN repetition reported.  The path's only collective -- the 32-byte statistics
     # all-reduce -- runs inside the timed region once per logging interval of LOG_INTERVAL lock-steps, the reference's
     # own cadence (main.py:194-: every log_interval = 10 updates of num_steps = 5 lock-steps).
@@ -329,11 +364,11 @@ def main():
 
     def timed_region(sets=None, log=True):
         fence()
-        # HIP events around the launches of every 8th region (and regions 2-4): recording a pair costs ~10 us of
+        # HIP events around the launches of every 16th region (and regions 2-4): recording a pair costs ~10 us of
         # host time, which a region of 20 lock-steps would feel
         kind = "past_l3" if sets is not None and sets is not only_sets else "headline"
         region_count[kind] = region_count.get(kind, 0) + 1
-        sampled = 2 <= region_count[kind] <= 4 or region_count[kind] % 8 == 0      # (a leg's first region runs cold)
+        sampled = 2 <= region_count[kind] <= 4 or region_count[kind] % 16 == 0      # (a leg's first region runs cold)
         if sampled:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -365,7 +400,7 @@ def main():
         samples += [timed_region(sets, log) for _ in range(more)]
         return all_max(samples)
 
-    samples = repeat_for(0.21, only_sets)
+    samples = repeat_for(args.gpu_seconds, only_sets)
     reps = len(samples)
     dt = sorted(samples)[len(samples) // 2]
     stats.collect(env).all_reduce()   # whatever finished since the last logging point (outside the timed regions)
@@ -413,7 +448,7 @@ def main():
         R = max(3, int(1.07e9 / set_bytes) + 1)
         sets = env.output_sets(R)
         drive(2 * R, sets)
-        s_l3 = repeat_for(0.1, sets, log=False)
+        s_l3 = repeat_for(args.gpu_seconds * 2.0 / 3.0, sets, log=False)
         reps_l3 = len(s_l3)
         dt_l3 = sorted(s_l3)[len(s_l3) // 2]
         kern_l3_ms = region_launch_ms("past_l3") or sorted(event_timed(n_ev, sets) for _ in range(3))[1]
@@ -496,7 +531,7 @@ def main():
                          "valu_utilisation": (ev or {}).get("valu_utilisation"),
                          "limiter": limiter(moved_l3, (ev or {}).get("valu_utilisation")),
                          "bytes_per_env_step": b_alg, "launch_us": kern_avg_ms * 1e3,
-                         "launch_us_is": ("HIP events on the launch stream around the K step-kernel launches of every 8th timed region, median "
+                         "launch_us_is": ("HIP events on the launch stream around the K step-kernel launches of every 16th timed region, median "
                                           "over the regions of elapsed / K (at small K this includes the idle gap in front of a region's "
                                           "first kernel; launch_us_back_to_back = one event pair around >= 200 queued launches)" if not args.stream else
                                           "HIP event pairs around single launches (refill kernels run beside the lock-steps)"),

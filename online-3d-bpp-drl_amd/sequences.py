@@ -58,7 +58,7 @@ def from_dataset(path, container_size=(10, 10, 10), terminator=(10, 10, 10), fir
             raise ValueError("%s: the last entry of every row must be the terminator %r" % (path, term))
         return np.ascontiguousarray(np.roll(pool, -int(first_index), axis=0))
     import torch
-    trajs = torch.load(path, weights_only=False)
+    trajs = torch.load(path, weights_only=True)      # a list of lists of ints: no pickled code is ever needed or run
     n = len(trajs)
     seqs = [[tuple(int(v) for v in it) for it in trajs[(int(first_index) + r) % n]] for r in range(n)]
     for q in seqs:                   # a stored trailing terminator is the same thing as the padding

@@ -20,6 +20,9 @@ from .sequences import check_pool
 from .spaces import Box, Discrete
 
 
+STATE_FORMAT = 1      # state_dict()["format"]: 1 = 48-byte records whose last word is hmax, per-bin ep_acc rows
+
+
 class StepTensors(object):
     """Device-resident result of one lock-step (views of the env's output buffers unless the env was built with
     fresh_outputs=True).  Either built from ready tensors (keyword arguments), or -- what the env does -- over ONE flat
@@ -324,6 +327,8 @@ class BppVecEnv(object):
         self._tstart = time.time()
         self.closed = False
 
+    MAX_STAGING = 16     # page-locked host buffers (29 B per bin each) handed out at the same time, at most
+
     # ------------------------------------------------------------------ buffers
     def _layout(self):
         """Byte layout of one set of output buffers inside a single allocation (every region 256-byte aligned): obs,
@@ -363,12 +368,12 @@ class BppVecEnv(object):
         through the allocator: same lifetime rule as the caching allocator's (the next writer is a kernel on the caller's
         stream, ordered behind whatever was enqueued there before)."""
         regions, total, offs, hot = self._layout()
-        use_count = getattr(torch._C, "_storage_Use_Count", None) if self.fresh_outputs else None
+        use_count, idle = self._storage_use_count() if self.fresh_outputs else (None, 0)
         flat = out = None
         if use_count is not None:
             pool = self._out_pool
             for k, (f, o) in enumerate(pool):
-                if use_count(f.untyped_storage()._cdata) <= 2:      # the pool's tensor + the wrapper just made for the query
+                if use_count(f.untyped_storage()._cdata) <= idle:   # the pool's tensor + the wrapper just made for the query
                     flat, out = f, o
                     pool.append(pool.pop(k))
                     break
@@ -387,7 +392,30 @@ class BppVecEnv(object):
         res = StepTensors(_flat=flat, _layout=regions, _offs=offs, _stage=self._staging, _hot=hot)
         return res, out
 
-    def _staging(self):
+    def _storage_use_count(self):
+        """(torch's storage use-count query, its reading for a storage only ONE tensor refers to) -- or (None, 0) when
+        this torch build has no such query or it does not behave as expected.  Calibrated once per env: the reading of a
+        fresh tensor is the idle value, and it must rise by one when a second handle (`detach()`) exists; otherwise
+        output sets are never handed out again (plain allocation every step).  Holders of raw pointers or of a bare
+        `untyped_storage()` are NOT counted by torch: they do not keep an output set alive."""
+        cal = getattr(self, "_use_count_cal", None)
+        if cal is None:
+            fn, idle = getattr(torch._C, "_storage_Use_Count", None), 0
+            try:
+                t = torch.empty((16,), dtype=torch.uint8, device=self.device)
+                idle = fn(t.untyped_storage()._cdata)
+                d = t.detach()
+                if fn(t.untyped_storage()._cdata) != idle + 1:
+                    fn = None
+                del d
+                if fn is not None and fn(t.untyped_storage()._cdata) != idle:
+                    fn = None
+            except Exception:  # noqa: BLE001
+                fn = None
+            cal = self._use_count_cal = (fn, idle)
+        return cal
+
+    def _staging(self, mapped=False):
         """A page-locked host buffer (numpy uint8 view) for the per-bin scalars of a step that nobody else references:
         buffers handed out earlier come back into use only when every view of them (the CPU reward tensor, `done`) has
         been dropped -- checked by reference count --, otherwise a new one is pinned.  The reference loop copies reward
@@ -401,6 +429,13 @@ class BppVecEnv(object):
             if sys.getrefcount(a) <= 3:          # the pool's tuple, the loop variable, getrefcount's argument
                 pool.append(pool.pop(k))
                 return a
+        if len(pool) >= self.MAX_STAGING:       # a caller keeps every step's reward / done views alive: do not pin without bound
+            if not getattr(self, "_staging_warned", False):
+                import warnings
+                warnings.warn("%d page-locked step buffers are all still referenced; further steps use pageable host memory "
+                              "(slower) -- copy reward / done out of the step's views instead of keeping them" % len(pool), RuntimeWarning)
+                self._staging_warned = True
+            return None if mapped else np.empty((n,), dtype=np.uint8)    # (a kernel cannot write into pageable memory)
         t = torch.empty((n,), dtype=torch.uint8).pin_memory()
         a = t.numpy()
         pool.append((t, a))
@@ -554,20 +589,25 @@ class BppVecEnv(object):
     def step_async(self, actions):
         """The reference-shaped path: the step kernel also writes reward and done (5 bytes per bin) straight into a
         page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing."""
-        host = self._staging()
-        self._pending = (self.step_tensors(actions, _host=host), host)
+        host = self._staging(mapped=True)      # None: every page-locked buffer is still referenced -> step_wait() copies
+        res = self.step_tensors(actions, _host=host)
+        self._pending = (res, host, self._last_stream)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
 
     def step_wait(self):
         """(obs, reward, done, infos) with the reference's types (acktr/envs.py:189-193)."""
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
-        (r, host), self._pending = self._pending, None
-        rc = self.lib.bpp_wait(self._last_stream)   # the kernel wrote reward / done into `host` itself
-        if rc:
-            _lib.check(rc)
-        offs, E = self._layout()[2], self.E
-        rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
-        done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
+        (r, host, stream), self._pending = self._pending, None
+        if host is None:
+            rew, done = r.host_reward_done(stream)          # one 5-byte-per-bin copy + stream synchronise
+            done = done.view(np.bool_)
+        else:
+            rc = self.lib.bpp_wait(stream)   # the kernel wrote reward / done into `host` itself
+            if rc:
+                _lib.check(rc)
+            offs, E = self._layout()[2], self.E
+            rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
+            done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
 
@@ -684,7 +724,7 @@ class BppVecEnv(object):
         """Env checkpoint (the reference never checkpoints env state; a handful of tensors here): byte
         heightmaps, per-bin records, per-bin episode accumulators and -- so that a loop can resume mid-rollout -- the
         last observation and its mask."""
-        sd = {"hmap": self.hmap.clone(), "state": self.state.clone(), "ep_acc": self.ep_acc.clone(),
+        sd = {"format": STATE_FORMAT, "hmap": self.hmap.clone(), "state": self.state.clone(), "ep_acc": self.ep_acc.clone(),
               "first_reset": self._first_reset}
         if self._stream is not None:   # streaming supply: the ring, every bin's generator and its progress
             sd.update(stream_ring=self.pool.clone(), stream_mt=self._mt.clone(), stream_gen_next=self.gen_next.clone(),
@@ -714,10 +754,22 @@ class BppVecEnv(object):
                 raise ValueError("checkpoint stream_spec: ring / generator buffers have another shape than this env's")
         if tuple(sd["hmap"].shape) != tuple(self.hmap.shape):
             raise ValueError("checkpoint holds %r heightmaps, this env %r" % (tuple(sd["hmap"].shape), tuple(self.hmap.shape)))
+        fmt = int(sd.get("format", 0))
+        if fmt > STATE_FORMAT:
+            raise ValueError("checkpoint format %d is newer than this build's %d" % (fmt, STATE_FORMAT))
+        if "stats" in sd and "ep_acc" not in sd:
+            import warnings
+            warnings.warn("legacy checkpoint: its `stats` (slotted episode sums of ABI < 10) cannot be mapped onto the per-bin "
+                          "accumulators; episode statistics restart from zero", RuntimeWarning)
         self.hmap.copy_(sd["hmap"])
         self.state.copy_(sd["state"])
+        # bpp_env_state.hmax (word 11; `pad` before format 1) is derived data the 20x20 kernel trusts: always recompute
+        # it from the heightmaps instead of believing the checkpoint
+        self.state[:, 11] = self.hmap.max(dim=1).values.to(torch.int32)
         if "ep_acc" in sd:
             self.ep_acc.copy_(sd["ep_acc"])
+        else:
+            self.ep_acc.zero_()
         self._first_reset = bool(sd["first_reset"])
         if self._stream is not None:
             self.pool.copy_(sd["stream_ring"])

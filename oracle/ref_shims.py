@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- import shims that let the *unmodified* reference run in
 the build container (no `gym`, no `transforms3d` installed there).
 
-Only `tests/`, `tests/golden/make_golden.py` and `oracle/time_reference.py` may import this
-module.  The product package never does.  Nothing here restates reference logic: the shims are the
+Only `tests/`, `tests/golden/make_golden.py`, `oracle/ref_baseline.py` (bench.py's cpu_baseline leg) and
+`oracle/time_reference.py` may import this module.  The product package never does.  Nothing here restates reference logic: the shims are the
 minimal surface of two third-party packages the reference imports:
 
 * `gym`            -- Env / Wrapper / ObservationWrapper / spaces.{Discrete,Box,Dict,Tuple} /
@@ -11,7 +11,10 @@ minimal surface of two third-party packages the reference imports:
                       baselines/common/vec_env/util.py)
 * `transforms3d.euler` -- quat2euler / quat2mat (decorative in envs/bpp0/mdCreator.py:19,33)
 
-`/root/reference` exists only in the build container; `available()` says whether it is there.
+`/root/reference` exists only in the build container.  On the GPU box the reference is `oracle/_ref/`: byte-for-byte
+copies of the files the env side loads, made by the committed recipe `oracle/make_ref.py` (git-ignored, travels with the
+working tree).  `available()`: is either of them there?  `install(root=...)` picks one explicitly; bench.py and the
+`-m gpu` tests always pass `REF_COPY` (they must not read /root/reference at run time).
 """
 import os
 import sys
@@ -19,11 +22,30 @@ import types
 
 import numpy as np
 
-REFERENCE_ROOT = os.environ.get("BPP_REFERENCE_ROOT", "/root/reference")
+REF_COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _is_tree(root):
+    return bool(root) and os.path.isfile(os.path.join(root, "envs", "bpp0", "bin3D.py"))
+
+
+def _default_root():
+    env = os.environ.get("BPP_REFERENCE_ROOT")
+    if env:
+        return env
+    return "/root/reference" if _is_tree("/root/reference") or not _is_tree(REF_COPY) else REF_COPY
+
+
+REFERENCE_ROOT = _default_root()
 
 
 def available():
-    return os.path.isfile(os.path.join(REFERENCE_ROOT, "envs", "bpp0", "bin3D.py"))
+    return _is_tree(REFERENCE_ROOT)
+
+
+def copy_available():
+    """oracle/_ref/ (made by oracle/make_ref.py) is there."""
+    return _is_tree(REF_COPY) and os.path.isfile(os.path.join(REF_COPY, "MANIFEST.json"))
 
 
 class _Space(object):
@@ -141,8 +163,15 @@ def _make(id, **kwargs):
     return getattr(importlib.import_module(mod), cls)(**kwargs)
 
 
-def install():
-    """Register the fake modules and put the reference root on sys.path (idempotent)."""
+def install(root=None):
+    """Register the fake modules and put the reference root on sys.path (idempotent; one root per process)."""
+    global REFERENCE_ROOT
+    if root is not None:
+        root = os.path.abspath(root)
+        loaded = getattr(sys.modules.get("envs.bpp0"), "__file__", None)
+        if loaded and not os.path.abspath(loaded).startswith(root + os.sep):
+            raise RuntimeError("reference already imported from %s, cannot switch to %s" % (loaded, root))
+        REFERENCE_ROOT = root
     if not available():
         raise RuntimeError("reference tree not found at %s" % REFERENCE_ROOT)
     if "gym" not in sys.modules:

@@ -92,7 +92,8 @@ def exact(a, dtype):
     return b
 
 
-def rollout_case(name, pool, size, rotation, E, steps, seed, p_random):
+def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=None):
+    """One recorded rollout of the reference stack -> <out_dir or tests/golden>/<name>.npz."""
     W, L, H = size
     A = W * L
     M = A * (1 + rotation)
@@ -136,7 +137,7 @@ def rollout_case(name, pool, size, rotation, E, steps, seed, p_random):
                reward=np.stack(rews), done=np.stack(dones), counter=np.stack(counters), ratio=np.stack(ratios),
                ep_r=np.stack(ep_r), ep_r_raw=np.stack(ep_r_raw), ep_l=np.stack(ep_l), pool=pool,
                size=np.array(size, np.int32), rotation=np.int32(rotation))
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(out_dir or HERE, name + ".npz")
     np.savez_compressed(path, **rec)
     nd = int(rec["done"].sum())
     print("%-22s E=%d steps=%d episodes=%d  mean mask density %.3f  -> %s (%d KB)" % (
@@ -256,5 +257,80 @@ def main():
     mask_case("masks_7x13x8", (7, 13, 8), 200, 13, 1, 8)
 
 
+def live_case(spec_json):
+    """`make_golden.py --live '<json>'`: ONE rollout recorded NOW from whatever reference tree ref_shims resolves
+    (BPP_REFERENCE_ROOT; the GPU suite points it at oracle/_ref/), written to spec["out_dir"] -- the same format as the
+    committed fixtures, so the same checker replays it on the HIP path (tests/test_gpu_vs_live_reference.py).
+    spec: name, out_dir, size, rotation, E, steps, seed, p_random and either pool (npz path) or dataset (a
+    reference dataset/*.pt played through the reference's own LoadBoxCreator, binCreator.py:42-72)."""
+    import json
+    spec = json.loads(spec_json)
+    size = tuple(spec["size"])
+    if spec.get("dataset"):
+        dataset_case(spec["name"], spec["dataset"], size, spec["E"], spec["steps"], spec["seed"], spec["p_random"], spec["out_dir"])
+        return
+    pool = np.load(spec["pool"])["pool"]
+    rollout_case(spec["name"], pool, size, bool(spec["rotation"]), spec["E"], spec["steps"], spec["seed"], spec["p_random"],
+                 out_dir=spec["out_dir"])
+
+
+def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):
+    """E reference envs built the way `--load-dataset` builds them -- PackingGame(test=True, data_name=path): the
+    reference's LoadBoxCreator, unmodified -- whose creators start at trajectory index e (attribute set from outside;
+    LoadBoxCreator.reset pre-increments, so episode k of env e plays trajectory e + k + 1).  Recorded like
+    rollout_case; `pool` in the file holds sequences.from_dataset's rows of the same file."""
+    import contextlib
+    import io
+    import bpp_amd
+    from envs.bpp0.binCreator import LoadBoxCreator
+
+    def thunk(e):
+        def _t():
+            with contextlib.redirect_stdout(io.StringIO()):
+                env = PackingGame(container_size=size, test=True, data_name=path, enable_rotation=False)
+            assert isinstance(env.box_creator, LoadBoxCreator)
+            env.box_creator.index = e
+            return bench.Monitor(env, None, allow_early_resets=False)
+        return _t
+
+    dummy = DummyVecEnv([thunk(e) for e in range(E)])
+    venv = VecPyTorch(VecNormalize(dummy, gamma=1.0, ob=False, ret=False), torch.device("cpu"))
+    rng = np.random.RandomState(seed)
+    A = size[0] * size[1]
+    obs = venv.reset()
+    mask = loop_masks(obs, size, False)
+    rec = dict(obs0=exact(obs.numpy(), np.uint8), mask0=exact(mask, np.uint8), smask0=exact(space_masks(dummy), np.uint8))
+    keys = ("actions", "obs", "mask", "smask", "reward", "done", "counter", "ratio", "ep_r", "ep_l", "ep_r_raw")
+    cols = {k: [] for k in keys}
+    for _ in range(steps):
+        a = np.array([rng.randint(0, A) if rng.rand() < p_random else rng.choice(np.flatnonzero(mask[e])) for e in range(E)], np.int64)
+        obs, reward, done, infos = venv.step(torch.from_numpy(a).unsqueeze(1))
+        mask = loop_masks(obs, size, False)
+        cols["actions"].append(a)
+        cols["obs"].append(exact(obs.numpy(), np.uint8))
+        cols["mask"].append(exact(mask, np.uint8))
+        cols["smask"].append(exact(space_masks(dummy), np.uint8))
+        cols["reward"].append(reward.numpy()[:, 0].copy())
+        cols["done"].append(np.asarray(done).astype(np.uint8))
+        cols["counter"].append(np.array([i["counter"] for i in infos], np.int32))
+        cols["ratio"].append(np.array([float(i["ratio"]) for i in infos], np.float64))
+        cols["ep_r"].append(np.array([i["episode"]["r"] if "episode" in i else np.nan for i in infos], np.float64))
+        cols["ep_l"].append(np.array([i["episode"]["l"] if "episode" in i else -1 for i in infos], np.int32))
+        cols["ep_r_raw"].append(np.array([dummy.envs[e].episode_rewards[-1] if done[e] else np.nan for e in range(E)], np.float64))
+    rec.update({k: np.stack(v) for k, v in cols.items()})
+    # the device env's assignment rule is "episode k of bin g plays pool row (g + k * E) mod P" (include/bpp_abi.h); the
+    # creators above play trajectory g + k + 1 = from_dataset's row g + k: lay those rows out under that rule
+    ds = bpp_amd.sequences.from_dataset(path, size)
+    K = steps + 1                                   # an episode takes at least one lock-step
+    pool = np.empty((E * K,) + ds.shape[1:], np.uint8)
+    for k in range(K):
+        pool[k * E:(k + 1) * E] = ds[(np.arange(E) + k) % ds.shape[0]]
+    rec.update(pool=pool, size=np.array(size, np.int32), rotation=np.int32(0))
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--live":
+        live_case(sys.argv[2])
+    else:
+        main()

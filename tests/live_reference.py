@@ -1,0 +1,54 @@
+"""Test infrastructure shared by tests/test_oracle_vs_live_reference.py (CPU) and tests/test_gpu_vs_live_reference.py (GPU):
+rollouts recorded NOW, in child processes, from the unmodified reference in oracle/_ref/ (oracle/make_ref.py's copies --
+the only reference tree that exists on the GPU box), in the format of the committed golden fixtures.
+
+Cases (VERDICT r3, next-round #1 ii): 64 bins x 200 lock-steps of the reference stack (PackingGame + Monitor +
+DummyVecEnv + VecNormalize + VecPyTorch + the per-row acktr.utils mask loop of main.py:163-169) on the 10x10x10 bin,
+10x10x10 + rotation and 20x20x20 with the bench's CUT-2 pools, plus dataset/cut_2.pt played through the reference's own
+LoadBoxCreator.  The four recordings run side by side (one process each)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "live_cut2_10": dict(size=(10, 10, 10), rotation=False, E=64, steps=200, seed=41, p_random=0.06, pool=("cut2", 256)),
+    "live_cut2_10_rot": dict(size=(10, 10, 10), rotation=True, E=64, steps=200, seed=42, p_random=0.06, pool=("cut2", 256)),
+    "live_cut2_20": dict(size=(20, 20, 20), rotation=False, E=64, steps=200, seed=43, p_random=0.03, pool=("cut2", 96)),
+    # (LoadBoxCreator.reset re-reads the whole .pt file, ~0.7 s per episode: a smaller case)
+    "live_dataset_cut2": dict(size=(10, 10, 10), rotation=False, E=8, steps=60, seed=44, p_random=0.06, dataset="dataset/cut_2.pt"),
+}
+
+
+def record_all(out_dir, cases=None):
+    """Start one recording process per case against oracle/_ref/; returns {name: npz path}.  Raises with the child's
+    stderr if one fails."""
+    import bpp_amd
+    from oracle import ref_shims
+    assert ref_shims.copy_available(), "oracle/_ref/ is missing (python oracle/make_ref.py in the build container)"
+    env = dict(os.environ, BPP_REFERENCE_ROOT=ref_shims.REF_COPY, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    procs = {}
+    for name, c in CASES.items():
+        if cases is not None and name not in cases:
+            continue
+        spec = dict(name=name, out_dir=out_dir, size=list(c["size"]), rotation=c["rotation"], E=c["E"], steps=c["steps"],
+                    seed=c["seed"], p_random=c["p_random"])
+        if "dataset" in c:
+            spec["dataset"] = os.path.join(ref_shims.REF_COPY, c["dataset"])
+        else:
+            pool = bpp_amd.sequences.cut2_pool(c["size"], c["pool"][1], seed=7)
+            spec["pool"] = os.path.join(out_dir, name + "_pool.npz")
+            np.savez(spec["pool"], pool=pool)
+        procs[name] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py"), "--live", json.dumps(spec)],
+                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = {}
+    for name, p in procs.items():
+        so, se = p.communicate(timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError("recording %s from oracle/_ref failed:\n%s" % (name, se[-2000:]))
+        out[name] = os.path.join(out_dir, name + ".npz")
+    return out

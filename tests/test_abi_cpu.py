@@ -82,3 +82,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libbpp_oracle" not in txt, f
+                # ... nor the reference copies under oracle/_ref/ or the import shims that load them
+                assert "ref_shims" not in txt and "oracle/_ref" not in txt and "BPP_REFERENCE_ROOT" not in txt, f
+
+
+def test_bench_touches_the_reference_only_inside_the_cpu_baseline_leg():
+    """bench.py may execute oracle/ and oracle/_ref/ only as the reported CPU baseline; /root/reference never."""
+    txt = open(os.path.join(ROOT, "bench.py")).read()
+    assert "/root/reference" not in txt.replace("/root/reference is never read", "")
+    body = txt[txt.index("def main():"):]
+    assert "ref_shims" not in body and "ref_baseline" not in body and "from oracle" not in body

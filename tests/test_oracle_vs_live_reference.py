@@ -1,0 +1,28 @@
+"""CPU: the C oracle vs rollouts recorded at test time from oracle/_ref/ -- the copy of the reference that travels to
+the GPU box (tests/live_reference.py).  The GPU twin of this file replays the same kind of recordings on the HIP path."""
+import numpy as np
+import pytest
+
+import live_reference
+from oracle import ref_shims
+from test_oracle_golden import check_rollout
+
+pytestmark = pytest.mark.skipif(not ref_shims.copy_available(), reason="oracle/_ref/ not made (python oracle/make_ref.py)")
+
+
+@pytest.fixture(scope="module")
+def recordings(tmp_path_factory):
+    return live_reference.record_all(str(tmp_path_factory.mktemp("live_ref")))
+
+
+@pytest.mark.parametrize("case", sorted(live_reference.CASES))
+def test_oracle_replays_live_reference_recording(oracle, recordings, case):
+    g = dict(np.load(recordings[case]))
+    check_rollout(lambda pool, size, rot, E, rule: oracle.OracleEnv(pool, size, rot, E, mask_rule=rule), g)
+    assert g["done"].sum() > (200 if g["actions"].shape[1] >= 64 else 30)     # a real number of episodes went through the recording
+
+
+def test_ref_copy_is_byte_identical_to_the_reference_tree():
+    """oracle/_ref/ against its manifest -- and against /root/reference where that exists (the build container)."""
+    from oracle import make_ref
+    assert make_ref.check() == []

@@ -101,27 +101,16 @@ class _EmuVecEnvs(object):
 
 @pytest.mark.parametrize("rot", [False, True])
 def test_the_training_loop_of_main_py_runs_on_the_environment(emu, rot, tmp_path, capsys):
-    """The WHOLE loop of main.py:100-207, transcribed statement by statement (the file itself cannot be imported here:
-    tensorboardX and time.clock are missing), for three updates: factory-shaped env object, the per-observation mask
-    helpers with the reference's signatures, the infos scan, masks / bad_masks, the reference's RolloutStorage, Policy,
-    ACKTR update, the save path through utils.get_vec_normalize and the logging block.  The environment side runs the
-    product kernels on the host emulator; the masks the loop computes are checked against the reference's own helper."""
-    import os
-    from collections import deque
+    """The WHOLE loop of main.py:100-207, transcribed statement by statement (tests/main_loop.py; the file itself cannot be
+    imported here: tensorboardX and time.clock are missing), for three updates: factory-shaped env object, the
+    per-observation mask helpers with the reference's signatures, the infos scan, masks / bad_masks, the reference's
+    RolloutStorage, Policy, ACKTR update, the save path through utils.get_vec_normalize and the logging block.  The
+    environment side runs the product kernels on the host emulator; the masks the loop computes are checked against the
+    reference's own helper.  (tests/test_gpu_vs_live_reference.py runs the same loop on the HIP path.)"""
+    import main_loop
     ref_shims.install()
-    from acktr import algo, utils
-    from acktr.envs import VecNormalize          # noqa: F401
-    from acktr.model import Policy
-    from acktr.storage import RolloutStorage
-    from acktr.utils import get_possible_position as ref_gpp, get_rotation_mask as ref_grm
-
-    size = (10, 10, 10)
-    args = types.SimpleNamespace(channel=4, container_size=size, pallet_size=10, enable_rotation=rot, num_processes=6,
-                                 num_steps=5, hidden_size=256, gamma=1.0, save_model=True, save_interval=1, save_dir="x",
-                                 log_interval=1, algorithm="a2c", value_loss_coef=0.5, entropy_coef=0.01, invalid_coef=2.0,
-                                 lr=7e-4, eps=1e-5, alpha=0.99, tensorboard=False, device="cpu")
-    env_name, custom, time_now, data_path = "Bpp-v0", "test", "now", str(tmp_path)
-    KFAC = os.environ.get("BPP_TEST_KFAC", "0") == "1"
+    args = main_loop.default_args(rot)
+    size = args.container_size
 
     # the mask helpers with the reference's signatures (acktr/utils.py:37,64), served by the emulated mask kernel
     def get_possible_position(observation, container_size):
@@ -130,82 +119,7 @@ def test_the_training_loop_of_main_py_runs_on_the_environment(emu, rot, tmp_path
     def get_rotation_mask(observation, container_size):
         return emu.mask_from_obs(observation.numpy()[None], container_size, True)[0].astype(np.int32)
 
-    torch.manual_seed(1)
-    device = torch.device(args.device)
-    envs = _EmuVecEnvs(emu, bpp_amd.sequences.cut2_pool(size, 8, seed=0), size, rot, args.num_processes)   # main.py:63
-    actor_critic = Policy(envs.observation_space.shape, envs.action_space,
-                          base_kwargs={'recurrent': False, 'hidden_size': args.hidden_size, 'args': args})  # :80-82
-    actor_critic.to(device)
-    # main.py:105-110 (the 'acktr' branch; its 'a2c' branch omits args= and cannot run in the reference either).
-    # acktr=KFAC: K-FAC itself where its eigendecomposition converges on this tiny batch, else the same update with RMSprop
-    agent = algo.ACKTR(actor_critic, args.value_loss_coef, args.entropy_coef, args.invalid_coef, acktr=KFAC, args=args,
-                       **({} if KFAC else dict(lr=args.lr, eps=args.eps, alpha=args.alpha, max_grad_norm=0.5)))
-    rollouts = RolloutStorage(args.num_steps, args.num_processes, envs.observation_space.shape, envs.action_space,
-                              actor_critic.recurrent_hidden_state_size, can_give_up=False,
-                              enable_rotation=args.enable_rotation, pallet_size=args.container_size[0])    # :112-119
-    obs = envs.reset()                                                                                        # :121
-    location_masks = []
-    for observation in obs:
-        if not args.enable_rotation:
-            box_mask = get_possible_position(observation, args.container_size)
-        else:
-            box_mask = get_rotation_mask(observation, args.container_size)
-        location_masks.append(box_mask)
-    location_masks = torch.FloatTensor(np.array(location_masks)).to(device)
-    rollouts.obs[0].copy_(obs)
-    rollouts.location_masks[0].copy_(location_masks)
-    rollouts.to(device)
-    episode_rewards = deque(maxlen=10)
-    episode_ratio = deque(maxlen=10)
-    import time
-    start = time.time()
-    j = 0
-    while j < 3:                                                                                              # `while True`
-        j += 1
-        for step in range(args.num_steps):
-            with torch.no_grad():
-                value, action, action_log_prob, recurrent_hidden_states = actor_critic.act(
-                    rollouts.obs[step], rollouts.recurrent_hidden_states[step], rollouts.masks[step], location_masks)
-            location_masks = []
-            obs, reward, done, infos = envs.step(action)
-            for i in range(len(infos)):
-                if 'episode' in infos[i].keys():
-                    episode_rewards.append(infos[i]['episode']['r'])
-                    episode_ratio.append(infos[i]['ratio'])
-            for observation in obs:
-                if not args.enable_rotation:
-                    box_mask = get_possible_position(observation, args.container_size)
-                    assert box_mask == ref_gpp(observation, args.container_size)        # the reference's own helper
-                else:
-                    box_mask = get_rotation_mask(observation, args.container_size)
-                    np.testing.assert_array_equal(box_mask, ref_grm(observation, args.container_size))
-                location_masks.append(box_mask)
-            location_masks = torch.FloatTensor(np.array(location_masks)).to(device)
-            masks = torch.FloatTensor([[0.0] if done_ else [1.0] for done_ in done])
-            bad_masks = torch.FloatTensor([[0.0] if 'bad_transition' in info.keys() else [1.0] for info in infos])
-            rollouts.insert(obs, recurrent_hidden_states, action, action_log_prob, value, reward, masks, bad_masks, location_masks)
-        with torch.no_grad():
-            next_value = actor_critic.get_value(rollouts.obs[-1], rollouts.recurrent_hidden_states[-1], rollouts.masks[-1]).detach()
-        rollouts.compute_returns(next_value, False, args.gamma, 0.95, False)
-        value_loss, action_loss, dist_entropy, prob_loss, graph_loss = agent.update(rollouts)
-        rollouts.after_update()
-        if args.save_model:
-            if (j % args.save_interval == 0) and args.save_dir != "":
-                torch.save([actor_critic.state_dict(), getattr(utils.get_vec_normalize(envs), 'ob_rms', None)],
-                           os.path.join(data_path, env_name + time_now + ".pt"))
-        if j % args.log_interval == 0 and len(episode_rewards) > 1:
-            total_num_steps = (j + 1) * args.num_processes * args.num_steps
-            end = time.time()
-            print("Updates {}, num timesteps {}, FPS {} \\n"
-                  "Last {} training episodes: mean/median reward {:.1f}/{:.1f}, min/max reward {:.1f}/{:.1f}\\n"
-                  "The dist entropy {:.5f}, The value loss {:.5f}, the action loss {:.5f}\\n"
-                  "The mean space ratio is {}\\n".format(j, total_num_steps, int(total_num_steps / (end - start)),
-                                                        len(episode_rewards), np.mean(episode_rewards), np.median(episode_rewards),
-                                                        np.min(episode_rewards), np.max(episode_rewards), dist_entropy, value_loss,
-                                                        action_loss, np.mean(episode_ratio)))
-    assert all(np.isfinite(float(v)) for v in (value_loss, action_loss, dist_entropy, prob_loss, graph_loss))
-    assert os.path.exists(os.path.join(data_path, env_name + time_now + ".pt"))
-    saved = torch.load(os.path.join(data_path, env_name + time_now + ".pt"), weights_only=False)
-    assert saved[1] is None and len(saved[0]) > 0
+    out = main_loop.run(args, lambda a, device: _EmuVecEnvs(emu, bpp_amd.sequences.cut2_pool(size, 8, seed=0), size, rot, a.num_processes),
+                        get_possible_position, get_rotation_mask, str(tmp_path), updates=3)
     # a random initial policy under the mask fails often: episodes did finish and went through the infos scan
-    assert len(episode_rewards) >= 1 and all(0.0 <= r <= 10.0 for r in episode_rewards)
+    assert len(out["episode_rewards"]) >= 1 and all(0.0 <= r <= 10.0 for r in out["episode_rewards"])
