@@ -268,6 +268,8 @@ def main():
     A = size[0] * size[1]
     M = A * (2 if args.rotation else 1)
     E = args.envs
+    if world > 1 and torch.cuda.is_available() and not os.environ.get("BPP_BENCH_ONE_DEVICE") and torch.cuda.device_count() > local_rank:
+        torch.cuda.set_device(local_rank)   # the rank's device is current before the library is loaded or anything launched
     if args.pool_file:
         # .npz ([P][T][4] `pool`) or a reference dataset/*.pt, played as the reference's LoadBoxCreator plays it (first
         # episode = trajectory 1; rows end in the terminator: the reference's literal (10,10,10) for its own 10x10x10

@@ -133,18 +133,6 @@ __device__ __forceinline__ void episode_acc_add(double *ep_acc, int e, double re
     a[2] = v2 + (double)len;
     a[3] = v3 + 1.0;
 }
-#ifdef BPP_LEGACY_STATS_ATOMICS
-// Diagnostic builds only (tools/stress_stats.py): the slotted float64 atomics of rounds 1-2, slot picked from the
-// workgroup index as in the build that lost adds, accumulated into g_legacy_slots BESIDE the per-bin rows.
-__device__ double g_legacy_slots[256 * 4];
-__device__ __forceinline__ void legacy_stats_add(int k, double ret, double ratio, int len) {
-    double *a = g_legacy_slots + 4 * (k & 255);
-    atomicAdd(a + 0, ret);
-    atomicAdd(a + 1, ratio);
-    atomicAdd(a + 2, (double)len);
-    atomicAdd(a + 3, 1.0);
-}
-#endif
 // Accumulators that every workgroup of a launch adds to: system scope, i.e. at the memory side.
 __device__ __forceinline__ void stat_add_shared(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -617,14 +605,10 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
     ma = 0;
     // (rare path -- items wider than 5 x 6, in the benchmark only the bin-sized terminator: kept rolled, an unrolled
     // copy of these loops was what set the kernels' scalar-register count and cost the 10x10 + rotation kernel a workgroup slot per CU)
-#ifndef BPP_EXP_UNROLL_BIG
 #pragma unroll 1
-#endif
     for (int a0 = 0; a0 < x; a0 += kTileX) {
         const int xa = min(kTileX, x - a0);
-#ifndef BPP_EXP_UNROLL_BIG
 #pragma unroll 1
-#endif
         for (int b0 = 0; b0 < y; b0 += kTileY) {
             const int yb = min(kTileY, y - b0);
             int m, c;
@@ -1765,6 +1749,83 @@ __global__ __launch_bounds__(BPP_REDUCE_LANES) void acc_reduce_kernel(double *ep
     reduce_tree_1024(s0, s1, s2, s3, acc);
 }
 
+// The same reduction spread over the chip (bpp_episode_acc_reduce with a scratch buffer).  The normative order has 1 024
+// partial sums, each ONE sequential chain over its strided rows -- so 1 024 lanes is all the parallelism there is, and in
+// one workgroup they share one CU's memory pipeline (2 MB at ~30 GB/s).  Here every workgroup owns kAccWideLanes of the
+// partials (16 consecutive rows = one 512-byte line group per load instruction), keeps kAccWideU rows per lane in
+// flight, publishes its partials to the caller's scratch buffer and takes a ticket; the last arriver runs the binary
+// tree over all 1 024 partials.  Hand-off per MI355X_MICROARCH.md (inter-workgroup visibility): plain stores ->
+// __syncthreads -> lane-0 agent-scope release -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer: agent-scope
+// acquire behind the ticket -> __syncthreads -> plain loads.
+#ifndef BPP_DRAIN_VMEM   // (the host emulator of tests/emu defines it away: there is no vector memory queue to drain)
+#define BPP_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // invisible to the compiler's waitcnt pass, which may drop its own
+#endif
+constexpr int kAccWideLanes = 16, kAccWideGroups = BPP_REDUCE_LANES / kAccWideLanes, kAccWideU = 16;
+__global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, int E, double *acc, int clear, double *scratch) {
+    static __shared__ double part[4][BPP_REDUCE_LANES];
+    static __shared__ int last;
+    const int t = threadIdx.x;
+    unsigned int *ticket = (unsigned int *)(scratch + 4 * BPP_REDUCE_LANES);
+    if (t < kAccWideLanes) {
+        const int r = blockIdx.x * kAccWideLanes + t;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int e = r;
+        for (; e + (kAccWideU - 1) * BPP_REDUCE_LANES < E; e += kAccWideU * BPP_REDUCE_LANES) {
+            double v[kAccWideU][4];
+#pragma unroll
+            for (int u = 0; u < kAccWideU; ++u) {
+                const double *a = (const double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
+                v[u][0] = a[0], v[u][1] = a[1], v[u][2] = a[2], v[u][3] = a[3];
+            }
+#pragma unroll
+            for (int u = 0; u < kAccWideU; ++u) {
+                s0 = s0 + v[u][0];
+                s1 = s1 + v[u][1];
+                s2 = s2 + v[u][2];
+                s3 = s3 + v[u][3];
+                if (clear) {
+                    double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
+                    a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
+                }
+            }
+        }
+        for (; e < E; e += BPP_REDUCE_LANES) {
+            double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
+            const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+            s0 = s0 + v0;
+            s1 = s1 + v1;
+            s2 = s2 + v2;
+            s3 = s3 + v3;
+            if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
+        }
+        scratch[0 * BPP_REDUCE_LANES + r] = s0;
+        scratch[1 * BPP_REDUCE_LANES + r] = s1;
+        scratch[2 * BPP_REDUCE_LANES + r] = s2;
+        scratch[3 * BPP_REDUCE_LANES + r] = s3;
+    }
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        BPP_DRAIN_VMEM();
+        const unsigned int n = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = n == (unsigned int)(kAccWideGroups - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int i = t; i < 4 * BPP_REDUCE_LANES; i += 256) (&part[0][0])[i] = scratch[i];
+    __syncthreads();
+    for (int d = BPP_REDUCE_LANES / 2; d > 0; d >>= 1) {
+        for (int r = t; r < d; r += 256) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[k][r] = part[k][r] + part[k][r + d];
+        }
+        __syncthreads();
+    }
+    if (t < 4) acc[t] = acc[t] + part[t][0];
+    if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next (stream-ordered) call
+}
+
 thread_local char g_err[256];
 
 int fail(int code, const char *msg) {
@@ -2102,7 +2163,7 @@ int bpp_launch_info(int32_t E, int32_t W, int32_t L, int32_t H, int32_t rotation
         const int off_mk = round16(nbw * A), off_rec = round16(off_mk + g.epw * M);
         const int off_bal = (off_rec + nbw * (int)sizeof(TileRec) + 7) & ~7;
         const int off_p = round16(off_bal + (npass > 2 ? g.epw * 2 * npass * 8 : 0));
-        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * (g.epw == 1 ? 1 : g.K) + BPP_TILE_LDS_PAD);   // TileGeo::KP
+        lds = (size_t)kTileWaves * (off_p + g.epw * (W + 1) * (L + 1) * 8 * (g.epw == 1 ? 1 : g.K));   // TileGeo::KP
         out[2] = nbw;
     }
     out[5] = (int32_t)lds;
@@ -2565,28 +2626,20 @@ int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *r
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
 
-int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *stream) {
+int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *scratch, void *stream) {
     if (!ep_acc || !acc) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: NULL pointer");
     if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: non-positive size");
     if ((uintptr_t)ep_acc & 31u) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: ep_acc must be 32-byte aligned");
-    hipLaunchKernelGGL(acc_reduce_kernel, dim3(1), dim3(BPP_REDUCE_LANES), 0, (hipStream_t)stream, ep_acc, E, acc, clear);
+    if (scratch != nullptr) {
+        if ((uintptr_t)scratch & 7u) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: scratch must be 8-byte aligned");
+        hipLaunchKernelGGL(acc_reduce_wide_kernel, dim3(kAccWideGroups), dim3(256), 0, (hipStream_t)stream, ep_acc, E, acc, clear,
+                           (double *)scratch);
+    } else {
+        hipLaunchKernelGGL(acc_reduce_kernel, dim3(1), dim3(BPP_REDUCE_LANES), 0, (hipStream_t)stream, ep_acc, E, acc, clear);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
 
-#ifdef BPP_LEGACY_STATS_ATOMICS
-// diagnostic builds only (tools/stress_stats.py): read (and optionally clear) the slotted-atomics accumulators
-int bpp_debug_legacy_slots(double *host_out, int clear) {
-    if (!host_out) return fail(BPP_E_BADARG, "bpp_debug_legacy_slots: NULL");
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_legacy_slots), 256 * 4 * 8, 0, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol");
-    if (clear) {
-        std::vector<double> z(256 * 4, 0.0);
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_legacy_slots), z.data(), z.size() * 8, 0, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyToSymbol");
-    }
-    return 0;
-}
-#endif
 
 }  // extern "C"

@@ -34,33 +34,12 @@ constexpr CandMagicTable make_cand_magic() {
 __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
-// experiment switches of tools/build_variant.sh (defaults = the product): length-specialised candidate loops on / off,
-// extra LDS bytes per wave (lowers the number of workgroups a CU holds)
-#ifndef BPP_TILE_SPEC
-#define BPP_TILE_SPEC 1
-#endif
-#ifndef BPP_TILE_LDS_PAD
-#define BPP_TILE_LDS_PAD 0
-#endif
-// Where a finishing bin's episode-accumulator row is read and written back.  Measured on one box, 10x10 / + rotation,
-// one output set | outputs rotated past the Infinity Cache (profiles/r3x_ab_r3aa.txt):
-//   0  read behind the second barrier, added and stored at once: 28.37 | 33.08, 34.61 | 39.17 us -- past the Infinity
-//      Cache the 2 MB of rows are DRAM reads, a latency on the deciding wave's path;
-//   1  read up front with the state record by EVERY bin, values kept: 28.76 | 31.36, 35.10 | 36.38 us (eight more live
-//      registers through the decision);
-//   3  read up front by every bin AS A PREFETCH (the values are dead unless the bin finishes), read again behind the
-//      second barrier by the finishing bins -- now a cache hit --, added and stored at the END of the kernel:
-//      28.46 | 30.59, 34.75 | 36.19 us;
-//   4  like 1, stored at the end: 28.81 | 31.27 us;  2  like 0, stored at the end: no better than 0.
-// -> mode 3 where a wave owns several bins; the 20x20 kernel (one bin per wave, already at its memory floor past the
-// Infinity Cache) keeps mode 0 (mode 3 there: 57.6 -> 58.4 | 57.6 -> 60.1 us).  BPP_TILE_ACC_MODE overrides (experiments).
-#ifndef BPP_TILE_ACC_MODE
-#define BPP_TILE_ACC_MODE (-1)
-#endif
-#ifndef BPP_EXP_FORCE_LOW
-#define BPP_EXP_FORCE_LOW 0    // 1: TIMING EXPERIMENT ONLY (wrong masks for tall bins): 20x20 always on the one-word path, LDS sized for it
-#endif
-
+// Where a finishing bin's episode-accumulator row is read and written back (A/B of round 3, profiles/r3x_ab_r3aa.txt;
+// the rejected forms live there, not here).  kAccLate (a wave owns several bins): every bin reads its row up front with
+// the state record AS A PREFETCH (the values are dead unless the bin finishes), the finishing bins read it again behind
+// the second barrier -- now a cache hit -- and add / store it at the END of the kernel: 10x10 past the Infinity Cache
+// 33.1 -> 30.6 us.  One bin per wave (20x20, already at its memory floor there): read behind the second barrier, added
+// and stored at once.
 // Constants of one (bin, orientation) of the item on display: computed lane-parallel for all the wave's bins at once
 // (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
 // candidate loop with v_readlane -- no LDS round trip, ~100 scalar instructions per bin saved.
@@ -72,12 +51,7 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 //   w6: hash32(seed, global bin id, step) of the fused draw
 // Per-bin record in LDS written by the deciding wave (or, in the mask-only modes, by the owning wave), read by the
 // bin's lanes: 12 bytes.
-#ifdef BPP_EXP_REC16
-struct __attribute__((aligned(16))) TileRec {
-    uint32_t pad_;
-#else
 struct TileRec {
-#endif
     uint32_t item;   // item shown in the next observation: x | y<<8 | z<<16
     uint32_t place;  // lx | ly<<8 | x<<16 | y<<24 of the box just placed
     uint32_t flags;  // bit0 placed, bit1 reset (zero the map), bit2 every height of the bin <= kLowTop, bits 8.. new top height
@@ -131,7 +105,7 @@ struct TileGeo {
     // A wave that owns ONE bin (20x20) only ever holds a ONE-word prefix image: a bin taller than kLowTop is scanned
     // in two phases, upper word then lower word, in the same 3.5 KB (8 workgroups per CU instead of 5 with a two-word image).
     static constexpr int KP = (K == 2 && EPW == 1) ? 1 : K;
-    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * KP + BPP_TILE_LDS_PAD;  // prefix image of the current group
+    static constexpr int LDS_WAVE = OFF_P + EPW * PN * 8 * KP;  // prefix image of the current group
     static constexpr int LDS_BLOCK = kTileWaves * LDS_WAVE;
     static_assert(A % 4 == 0, "tile kernel needs W*L % 4 == 0");
     static_assert(L + 1 <= 32 && A < 2048, "slot word w1 holds nj in 5 bits and nv in 11");
@@ -145,7 +119,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     constexpr int A = T::A, A4 = T::A4, M = T::M, M4 = T::M4, PW = T::PW, PN = T::PN, G = T::G, NB = T::NB, LPB = T::LPB;
     constexpr int NPASS = T::NPASS, NBW = T::NBW;
     constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
-    constexpr int kAccMode = BPP_TILE_ACC_MODE >= 0 ? BPP_TILE_ACC_MODE : (EPW > 1 ? 3 : 0);
+    constexpr bool kAccLate = EPW > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,7 +152,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
     if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
         st0 = p.state[dec_e];
         act0 = p.actions[dec_e];
-        if constexpr (kAccMode == 1 || kAccMode == 3 || kAccMode == 4) {   // the row of EVERY bin, read with the state record
+        if constexpr (kAccLate) {   // the row of EVERY bin, read with the state record (a prefetch: see kAccLate above)
             if (p.ep_acc != nullptr && !BPP_ABL(p, 128)) {
                 const double *ea0 = (const double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
                 acc0 = ea0[0], acc1 = ea0[1], acc2 = ea0[2], acc3 = ea0[3];
@@ -453,15 +427,8 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         // latency overlaps the stores below
         const bool acc = p.ep_acc != nullptr && fin && !BPP_ABL(p, 128);
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)e, 32);
-        double a0 = acc0, a1 = acc1, a2 = acc2, a3 = acc3;
-        if constexpr (kAccMode == 0) {
-            if (acc) a0 = ea[0], a1 = ea[1], a2 = ea[2], a3 = ea[3];
-        } else if constexpr (kAccMode == 2 || kAccMode == 3) {
-            if (acc) acc0 = ea[0], acc1 = ea[1], acc2 = ea[2], acc3 = ea[3];   // consumed at the end of the kernel
-            acc_late = acc;
-        } else if constexpr (kAccMode == 4) {
-            acc_late = acc;
-        }
+        if (acc) acc0 = ea[0], acc1 = ea[1], acc2 = ea[2], acc3 = ea[3];
+        if constexpr (kAccLate) acc_late = acc;                             // consumed at the end of the kernel
         p.reward[e] = out_rew;
         p.done[e] = out_ok ? 0 : 1;
         if (p.host_reward) {        // mirrors in mapped host memory: step_wait() then only waits for the stream
@@ -473,15 +440,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         p.ep_ret[e] = fin_ret;
         p.ep_len[e] = fin_len;
         p.state[e] = st_out;
-        if (kAccMode <= 1 && acc) {
-            ea[0] = a0 + fin_ret;
-            ea[1] = a1 + fin_ratio;
-            ea[2] = a2 + (double)fin_len;
-            ea[3] = a3 + 1.0;
+        if (!kAccLate && acc) {
+            ea[0] = acc0 + fin_ret;
+            ea[1] = acc1 + fin_ratio;
+            ea[2] = acc2 + (double)fin_len;
+            ea[3] = acc3 + 1.0;
         }
-#ifdef BPP_LEGACY_STATS_ATOMICS
-        if (fin) legacy_stats_add(blockIdx.x >> 3, fin_ret, fin_ratio, fin_len);
-#endif
     }
 
     // ---- the wave's NIT groups of EPW bins, one after the other ------------------------------------------
@@ -580,7 +544,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 low = __ballot(mx > (uint32_t)kLowTop) == 0ull;
             }
         }
-        if (BPP_EXP_FORCE_LOW && K == 2 && EPW == 1) low = true;
         constexpr bool kTwoPhase = K == 2 && EPW == 1;         // tall bins: two one-word scans instead of one two-word scan
         uint32_t anymask = 0;                                  // bit b: bin b of the group has a feasible position
         // PH = 0: one scan (all levels in the image); 1: first scan of a tall bin -- the image holds the UPPER word, a
@@ -781,7 +744,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
                 using FF = std::false_type;
                 using I0 = std::integral_constant<int, 0>;
                 // length-specialised loops: the 20x20x20 step and mask kernels (resets only see empty maps)
-                constexpr bool kSpec = BPP_TILE_SPEC && EPW == 1 && W == 20 && L == 20 && K == 2 && !kResetsOnly;
+                constexpr bool kSpec = EPW == 1 && W == 20 && L == 20 && K == 2 && !kResetsOnly;
                 if (fresh) {
                     run(FF{}, TT{}, I0{});
                 } else if (big) {
@@ -883,7 +846,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
         }
         if (it == NIT - 1) BPP_STAMP(p, 10);
     }
-    if (kAccMode >= 2 && MODE == kStep && wid == 0 && acc_late) {   // the row read behind the second barrier has long arrived
+    if (kAccLate && MODE == kStep && wid == 0 && acc_late) {   // the row read behind the second barrier has long arrived
         double *ea = (double *)__builtin_assume_aligned(p.ep_acc + 4 * (size_t)dec_e, 32);
         ea[0] = acc0 + fin_ret;
         ea[1] = acc1 + fin_ratio;

@@ -28,7 +28,7 @@ class EpisodeStats(object):
 
     def collect(self, env, reset=True):
         """Add (and by default clear) the statistics BppVecEnv accumulated inside its step kernels."""
-        self.acc += env.episode_stats(reset=reset)
+        env.episode_stats(reset=reset, out=self.acc)      # the reduction kernel adds into self.acc itself
         return self
 
     def update(self, res):

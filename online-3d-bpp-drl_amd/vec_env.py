@@ -643,14 +643,27 @@ class BppVecEnv(object):
             _lib.check(rc)
         return out
 
-    def episode_stats(self, reset=False):
+    def episode_stats(self, reset=False, wide=True, out=None):
         """float64 [4] device tensor: sum of episode returns, sum of final ratios, sum of episode lengths,
         number of episodes finished since the last reset of the accumulators (main.py:159-162).  The per-bin rows
-        (`ep_acc` [E,4]) are summed in the fixed order of include/bpp_abi.h: the result is bit-reproducible."""
-        acc = torch.zeros((4,), dtype=torch.float64, device=self.device)
+        (`ep_acc` [E,4]) are summed in the fixed order of include/bpp_abi.h: the result is bit-reproducible.
+        wide=True: the 1 024 partial sums are computed by 64 workgroups through a scratch buffer (same additions, same
+        order, same bits; ~10x shorter than the one-workgroup form, which wide=False selects).  out: float64 [4] device
+        tensor the sums are ADDED to (no temporary, no extra launch)."""
+        if out is not None:
+            if out.device != self.device or out.dtype != torch.float64 or out.numel() != 4 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float64 [4] tensor on the env's device")
+            acc = out
+        else:
+            acc = torch.zeros((4,), dtype=torch.float64, device=self.device)
         self._on_device()
+        scratch = None
+        if wide:
+            scratch = getattr(self, "_reduce_scratch", None)
+            if scratch is None:     # zero-filled once; every call leaves its arrival counter at zero again
+                scratch = self._reduce_scratch = torch.zeros((_lib.REDUCE_SCRATCH_BYTES // 8,), dtype=torch.float64, device=self.device)
         _lib.check(self.lib.bpp_episode_acc_reduce(self.ep_acc.data_ptr(), self.E, acc.data_ptr(), int(bool(reset)),
-                                                   self._stream_ptr()))
+                                                   scratch.data_ptr() if scratch is not None else None, self._stream_ptr()))
         return acc
 
     # ------------------------------------------------------------------ lookahead support (SURVEY 8 f4)

@@ -449,7 +449,8 @@ int bpp_episode_stats(const uint8_t *done, const double *ep_ret, const double *r
     return 0;
 }
 
-int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *stream) {
+int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear, void *scratch, void *stream) {
+    (void)scratch;
     (void)stream;
     if (!ep_acc || !acc) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: NULL pointer");
     if (E <= 0) return fail(BPP_E_BADARG, "bpp_episode_acc_reduce: non-positive size");

@@ -109,7 +109,7 @@ def lib():
                                                  ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
                                                  ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
-        L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -199,10 +199,15 @@ class OracleEnv(object):
         self._after_steps(1)
         return self.out["obs"].copy(), self.out["mask"].copy()
 
-    def episode_stats(self, reset=False):
-        """float64 [4]: the per-bin accumulators summed in the ABI's fixed order (bpp_episode_acc_reduce)."""
+    def episode_stats(self, reset=False, wide=False):
+        """float64 [4]: the per-bin accumulators summed in the ABI's fixed order (bpp_episode_acc_reduce).  wide: hand the
+        library a scratch buffer (the oracle ignores it; the emulated product then runs its many-workgroup form)."""
         acc = np.zeros(4, np.float64)
-        _check(lib().bpp_episode_acc_reduce(_p(self.ep_acc), self.E, _p(acc), int(bool(reset)), None))
+        scratch = np.zeros(1024 * 4 + 8, np.float64) if wide else None
+        _check(lib().bpp_episode_acc_reduce(_p(self.ep_acc), self.E, _p(acc), int(bool(reset)),
+                                            _p(scratch) if wide else None, None))
+        if wide:
+            assert scratch[1024 * 4:].view(np.uint32)[0] == 0, "the arrival counter must be left at zero"
         return acc
 
     def step(self, actions, copy=True):

@@ -198,6 +198,10 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t se
     return r;
 }
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define BPP_DRAIN_VMEM() ((void)0)   // the product's `s_waitcnt vmcnt(0)` (inline gfx950 asm): nothing to drain here
+template <typename T>
+static inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }
 static inline uint32_t __builtin_amdgcn_s_getreg(int) { return 0; }   // hardware registers read as 0 here (one XCC)
 template <typename T>
 static inline T __hip_atomic_fetch_add(T *p, T v, int, int) {

@@ -82,6 +82,10 @@ def test_emulated_vs_oracle_random_rollout(emu, oracle, variant, size, rot, E, s
                 np.testing.assert_array_equal(env.state[f], ref.state[f], err_msg=f)
         np.testing.assert_array_equal(env.ep_acc, ref.ep_acc)
         np.testing.assert_array_equal(env.episode_stats(), ref.episode_stats())
+        # the many-workgroup form of the reduction (scratch buffer, last arriver runs the tree): same bits, rows cleared
+        np.testing.assert_array_equal(env.episode_stats(wide=True), ref.episode_stats())
+        np.testing.assert_array_equal(env.episode_stats(reset=True, wide=True), ref.episode_stats(reset=True))
+        assert not env.ep_acc.any() and not env.episode_stats(wide=True).any()
 
 
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 99), ((10, 10, 10), True, 70), ((20, 20, 20), False, 11),
@@ -244,3 +248,25 @@ def test_emulated_step_mirrors_reward_and_done_into_host_buffers(emu, oracle, va
             env.step(a)
         env._o.host_reward = None
         env.step(a)
+
+
+def test_emulated_wide_reduction_equals_the_one_workgroup_form_on_many_rows(emu, oracle):
+    """bpp_episode_acc_reduce with and without a scratch buffer on 5 000 rows of awkward float64 values (sizes that are not
+    a multiple of 1 024, rows past the unrolled part): identical bits, identical to the oracle's fixed order."""
+    import ctypes
+    rng = np.random.RandomState(5)
+    for E in (1, 15, 1024, 1025, 5000, 16 * 1024 + 3):
+        rows = (rng.rand(E, 4) * 10.0 ** rng.randint(-6, 6, size=(E, 4))).astype(np.float64)
+        got = {}
+        for name, lib, wide in (("oracle", oracle.lib(), False), ("emu_one", emu.lib(), False), ("emu_wide", emu.lib(), True)):
+            acc = np.array([1.5, -2.0, 0.25, 7.0])
+            buf = np.zeros(E * 4 + 4, np.float64)                      # the ABI wants the rows 32-byte aligned
+            off = (-buf.ctypes.data % 32) // 8
+            r = buf[off:off + 4 * E].reshape(E, 4)
+            r[:] = rows
+            scratch = np.zeros(1024 * 4 + 8, np.float64)
+            assert lib.bpp_episode_acc_reduce(r.ctypes.data, E, acc.ctypes.data, 1, scratch.ctypes.data if wide else None, None) == 0
+            assert not r.any()
+            got[name] = acc
+        np.testing.assert_array_equal(got["emu_one"], got["oracle"])
+        np.testing.assert_array_equal(got["emu_wide"], got["oracle"])

@@ -440,6 +440,7 @@ def test_gpu_long_soak_matches_oracle(bpp, oracle, size, rot, E, steps):
             np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
     np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
     got, want = env.episode_stats().cpu().numpy(), ref.episode_stats()
+    np.testing.assert_array_equal(env.episode_stats(wide=False).cpu().numpy(), want)   # one-workgroup form: the same bits
     np.testing.assert_array_equal(got, want)
     assert want[3] > E * steps / 60
 
@@ -613,6 +614,7 @@ def _lockstep_all_bins(bpp, oracle, size, rot, E, base, total, P, steps=12, seed
             np.testing.assert_array_equal(st[f], ref.state[f], err_msg=f)
     np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
     got, want = env.episode_stats().cpu().numpy(), ref.episode_stats()
+    np.testing.assert_array_equal(env.episode_stats(wide=False).cpu().numpy(), want)   # one-workgroup form: the same bits
     np.testing.assert_array_equal(got, want)
     assert finished > E // 4
 

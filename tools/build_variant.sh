@@ -1,8 +1,10 @@
 #!/bin/bash
 # Build a diagnostic / experimental variant of the product library next to it: tools/build_variant.sh <name> [-D...]
 #   -> online-3d-bpp-drl_amd/csrc/libbpp_hip_<name>.so; load it with BPP_HIP_LIB=<path> (never built implicitly).
-# Known variants: abl = -DBPP_ENABLE_ABLATION (phase ablation / timestamps), legacystats = -DBPP_LEGACY_STATS_ATOMICS
-# (tools/stress_stats.py: rounds 1-2's slotted float64 atomics kept beside the per-bin accumulators).
+# Known variant: abl = -DBPP_ENABLE_ABLATION (phase ablation / timestamps) -- the only switch the shipped source carries.
+# The A/B switches of rounds 2-3 (BPP_EXP_*, BPP_TILE_ACC_MODE / _SPEC / _LDS_PAD, BPP_LEGACY_STATS_ATOMICS) were removed
+# from the source in round 4; their measurements are profiles/r3x_* and profiles/r3_stress_stats_legacy_atomics.json, the
+# code is in the history (commit c585660).  New experiments: patch a copy, build it here, load it with BPP_HIP_LIB.
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../online-3d-bpp-drl_amd/csrc"

@@ -8,10 +8,10 @@ read-modify-write by the bin's own lane, fixed-order reduction) -- exact by cons
     alternating xcd_remap, interleaved allocator churn and a second stream hammering the L2s;
   * after every chunk compares the per-bin rows and their fixed-order reduction with the ORACLE bit for bit
     (assert_array_equal) -- the exactness claim of the new path;
-  * with BPP_HIP_LIB pointing at the diagnostic build (tools/build_variant.sh legacystats -DBPP_LEGACY_STATS_ATOMICS),
-    which keeps the OLD slotted atomics beside the rows, also compares the slot sums with the rows' sums and reports
-    every chunk in which the atomics path lost (or gained) adds -- either the r03f loss reproduces here, or this log
-    documents that it does not under the load we can generate.
+  * (round 3 only: a diagnostic build that kept the OLD slotted atomics beside the rows was compared as well --
+    profiles/r3_stress_stats_legacy_atomics.json: 20 000 launches, no add lost; that switch has since been removed from
+    the source, commit c585660 has it.  The `legacy` branches below only act when a library exports
+    bpp_debug_legacy_slots.)
 
     python tools/stress_stats.py --launches 12000          [BPP_HIP_LIB=.../libbpp_hip_legacystats.so]
 Prints one JSON line."""
