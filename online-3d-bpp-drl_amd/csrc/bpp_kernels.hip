@@ -1826,6 +1826,73 @@ __global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, in
     if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next (stream-ordered) call
 }
 
+// bpp_gather_finished: ordered compaction of the finished bins' per-bin outputs by ONE workgroup (64 KB of `done` per
+// 65 536 bins -- a few microseconds; the transfer to the host is what the call is about).  Thread t of a round owns 16
+// consecutive bins; exclusive prefix of the per-thread counts by wave shuffles + one LDS pass over the 16 waves.
+__global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
+                                                                const int32_t *ep_len, const int32_t *counter, int E,
+                                                                bpp_finished_row *rows) {
+    static __shared__ int wave_tot[16];
+    static __shared__ int wave_off[16];
+    static __shared__ int total;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int base = 0;
+    for (int c0 = 0; c0 < E; c0 += 1024 * 16) {
+        const int e0 = c0 + t * 16;
+        uint32_t m = 0;
+        if (e0 + 16 <= E && (((uintptr_t)(done + e0)) & 15u) == 0) {
+            const uint4 v = *(const uint4 *)(done + e0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m |= ((w[q] >> (8 * k)) & 255u) ? 1u << (4 * q + k) : 0u;
+        } else {
+            for (int k = 0; k < 16; ++k)
+                if (e0 + k < E && done[e0 + k]) m |= 1u << k;
+        }
+        const int cnt = __popc(m);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        if (t == 0) {
+            int s = 0;
+            for (int k = 0; k < 16; ++k) {
+                wave_off[k] = s;
+                s += wave_tot[k];
+            }
+            total = s;
+        }
+        __syncthreads();
+        int pos = 1 + base + wave_off[wave] + incl - cnt;     // row 0 is the header
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int e = e0 + k;
+            bpp_finished_row r;
+            r.ep_ret = ep_ret[e];
+            r.ratio = ratio[e];
+            r.ep_len = ep_len[e];
+            r.counter = counter[e];
+            r.bin = e;
+            r.reserved = 0;
+            rows[pos++] = r;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (t == 0) {
+        bpp_finished_row h;
+        h.ep_ret = 0.0, h.ratio = 0.0, h.ep_len = 0, h.counter = 0, h.bin = base, h.reserved = 0;
+        rows[0] = h;
+    }
+}
+
 thread_local char g_err[256];
 
 int fail(int code, const char *msg) {
@@ -2412,6 +2479,23 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
     e = hipStreamSynchronize((hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
+}
+
+int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
+                        const int32_t *counter, int32_t E, bpp_finished_row *rows_dev, bpp_finished_row *rows_host, int32_t n,
+                        void *stream) {
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !rows_dev || !rows_host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+    if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    hipLaunchKernelGGL(compact_finished_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
+                       rows_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    e = hipMemcpyAsync(rows_host, rows_dev, (size_t)(n + 1) * sizeof(bpp_finished_row), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
+    e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    if (rows_host[0].bin != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
+    return 0;
 }
 
 int bpp_wait(void *stream) {

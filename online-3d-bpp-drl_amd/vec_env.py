@@ -20,6 +20,7 @@ from .sequences import check_pool
 from .spaces import Box, Discrete
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 STATE_FORMAT = 1      # state_dict()["format"]: 1 = 48-byte records whose last word is hmax, per-bin ep_acc rows
 
 
@@ -145,8 +146,16 @@ class LazyInfos(object):
     def _finished(self):
         if self._fin is None:
             self._check_fresh()
-            idx = np.flatnonzero(self._done_mask())
             r = self._res
+            env = self._env
+            if getattr(r, "_flat", None) is not None and hasattr(env, "_gather_finished"):
+                # ONE native call (bpp_gather_finished): a launch compacts the finished bins' (r, ratio, l, counter, bin) rows on
+                # the device in bin order, one copy brings exactly those rows over
+                n = int(np.count_nonzero(self._done_mask()))
+                rows = env._gather_finished(r, n) if n else np.zeros((0,), env.FIN_ROW)
+                self._fin = (rows["bin"].astype(np.int64), np.stack([rows["ep_ret"], rows["ratio"]]), np.stack([rows["ep_len"], rows["counter"]]))
+                return self._fin
+            idx = np.flatnonzero(self._done_mask())
             if idx.size and torch.is_tensor(r.ep_ret):
                 it = torch.from_numpy(idx).to(r.ep_ret.device)
                 f64 = torch.stack([r.ep_ret[it], r.ratio[it]]).cpu().numpy()
@@ -156,6 +165,12 @@ class LazyInfos(object):
                 i32 = np.stack([r.ep_len.cpu().numpy()[idx], r.counter.cpu().numpy()[idx]])
             self._fin = (idx, f64, i32)
         return self._fin
+
+    def episodes(self):
+        """The episodes that finished in this step as arrays -- what main.py:159-162 collects one dict at a time:
+        {'bins': int64 [n], 'r': float64 [n] (rounded like Monitor's), 'l': int32 [n], 'ratio': float64 [n], 'counter': int32 [n]}."""
+        idx, f64, i32 = self._finished()
+        return {"bins": idx, "r": np.round(f64[0], 6), "l": i32[0], "ratio": f64[1], "counter": i32[1]}
 
     def _running(self):
         if self._live is None:
@@ -441,12 +456,43 @@ class BppVecEnv(object):
         pool.append((t, a))
         return a
 
+    FIN_ROW = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("bin", "<i4"),
+                        ("reserved", "<i4")])   # bpp_finished_row
+
+    def _gather_finished(self, res, n):
+        """The `n` finished bins of step result `res` as bpp_finished_row records in ascending bin order, through
+        bpp_gather_finished: one compaction launch, ONE device-to-host copy of n + 1 rows, stream synchronise.  The device and
+        page-locked staging areas ([E + 1] rows each) are allocated on first use."""
+        st = getattr(self, "_fin_stage", None)
+        if st is None:
+            nb = (self.E + 1) * self.FIN_ROW.itemsize
+            t = torch.empty((nb,), dtype=torch.uint8).pin_memory()
+            st = self._fin_stage = (t, t.numpy().view(self.FIN_ROW), torch.empty((nb,), dtype=torch.uint8, device=self.device))
+        _, hrows, drows = st
+        base, lay = res._flat.data_ptr(), res._layout
+        self._on_device()
+        _lib.check(self.lib.bpp_gather_finished(base + lay["done"][0], base + lay["ep_ret"][0], base + lay["ratio"][0],
+                                                base + lay["ep_len"][0], base + lay["counter"][0], self.E, drows.data_ptr(),
+                                                hrows.ctypes.data, int(n), self._stream_ptr()))
+        return hrows[1:n + 1].copy()
+
     def _buffers(self):
         if self.fresh_outputs or self._bufs is None:
             self._bufs, self._out = self._alloc()
         return self._bufs, self._out
 
+    @staticmethod
+    def _plain(out):
+        """Clear the per-call fields of a bpp_step_out (step_tensors sets them in place): no fused draw, no host mirrors."""
+        out.next_action = out.host_reward = out.host_done = None
+        return out
+
     def _stream_ptr(self):
+        """The calling thread's current HIP stream on the env's device as a c_void_p (raw handle straight from torch's
+        stream table -- a third of the cost of building a torch.cuda.Stream object per step)."""
+        raw = _RAW_STREAM
+        if raw is not None:
+            return ctypes.c_void_p(raw(self.device.index))
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def refill(self):
@@ -483,7 +529,7 @@ class BppVecEnv(object):
         mode = _lib.RESET_INIT if self._first_reset else _lib.RESET_ADVANCE
         if self._stream is not None and not self._first_reset:
             self.refill()              # RESET_ADVANCE moves every bin on by one episode
-        _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(out), self._stream_ptr()))
+        _lib.check(self.lib.bpp_reset(self._batch_ref, mode, ctypes.byref(self._plain(out)), self._stream_ptr()))
         self._serial += 1
         self._stepped()
         self._first_reset = False
@@ -510,18 +556,19 @@ class BppVecEnv(object):
         if self.fresh_outputs or self._bufs is None:
             self._bufs, self._out = self._alloc()
             self._res = self._bufs
-        out = self._out
+        out = self._out          # this output set's own bpp_step_out: the per-call fields are set in place (no struct copy)
         if sample is not None:
             seed, step, nxt = sample
             if nxt.device != self.device or nxt.dtype != torch.int64 or nxt.numel() != self.E or not nxt.is_contiguous():
                 raise ValueError("sample out tensor must be a contiguous int64 [E] tensor on the env's device")
-            out = _lib.StepOut.from_buffer_copy(self._out)
             out.next_action, out.sample_seed, out.sample_step = nxt.data_ptr(), int(seed), int(step)
+        else:
+            out.next_action = None
         if _host is not None:
-            if out is self._out:
-                out = _lib.StepOut.from_buffer_copy(self._out)
             offs, base = self._layout()[2], _host.ctypes.data
             out.host_reward, out.host_done = base + offs["reward"], base + offs["done"]
+        else:
+            out.host_reward = out.host_done = None
         self._last_stream = sp = self._stream_ptr()
         rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
         if rc:
@@ -546,11 +593,11 @@ class BppVecEnv(object):
         self._serial += int(nsteps)
         if self._stream is not None:
             self.refill()
-            _lib.check(self.lib.bpp_rollout_uniform_stream(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
+            _lib.check(self.lib.bpp_rollout_uniform_stream(self._batch_ref, ctypes.byref(self._plain(self._out)), actions.data_ptr(), int(seed),
                                                            int(step0), int(nsteps), ctypes.byref(self._stream),
                                                            self.refill_every, self._stream_ptr()))
             return self._res
-        _lib.check(self.lib.bpp_rollout_uniform(self._batch_ref, ctypes.byref(self._out), actions.data_ptr(), int(seed),
+        _lib.check(self.lib.bpp_rollout_uniform(self._batch_ref, ctypes.byref(self._plain(self._out)), actions.data_ptr(), int(seed),
                                                 int(step0), int(nsteps), self._stream_ptr()))
         return self._res
 
@@ -574,7 +621,7 @@ class BppVecEnv(object):
         if sets is None:
             sets = [(self._bufs, self._out)]
         n = len(sets)
-        outs = (_lib.StepOut * n)(*[o for _, o in sets])
+        outs = (_lib.StepOut * n)(*[self._plain(o) for _, o in sets])
         first = self.location_masks
         self._on_device()
         self._serial += int(nsteps)
@@ -586,11 +633,12 @@ class BppVecEnv(object):
             self._res = self._bufs
         return self._res
 
-    def step_async(self, actions):
+    def step_async(self, actions, sample=None):
         """The reference-shaped path: the step kernel also writes reward and done (5 bytes per bin) straight into a
-        page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing."""
+        page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing.
+        sample=(seed, step, out): as in step_tensors -- also draw a uniform-feasible action for the new observation."""
         host = self._staging(mapped=True)      # None: every page-locked buffer is still referenced -> step_wait() copies
-        res = self.step_tensors(actions, _host=host)
+        res = self.step_tensors(actions, sample=sample, _host=host)
         self._pending = (res, host, self._last_stream)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
 
     def step_wait(self):
@@ -611,8 +659,8 @@ class BppVecEnv(object):
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
 
-    def step(self, actions):
-        self.step_async(actions)
+    def step(self, actions, sample=None):
+        self.step_async(actions, sample=sample)
         return self.step_wait()
 
     def close(self):

@@ -466,6 +466,25 @@ int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear
     return 0;
 }
 
+int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
+                        const int32_t *counter, int32_t E, bpp_finished_row *rows_dev, bpp_finished_row *rows_host, int32_t n,
+                        void *stream) {
+    (void)stream;
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !rows_dev || !rows_host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+    if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    int k = 0;
+    for (int e = 0; e < E; ++e)
+        if (done[e]) {
+            bpp_finished_row r = {ep_ret[e], ratio[e], ep_len[e], counter[e], e, 0};
+            rows_dev[++k] = r;
+        }
+    bpp_finished_row h = {0.0, 0.0, 0, 0, k, 0};
+    rows_dev[0] = h;
+    if (k != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
+    memmove(rows_host, rows_dev, (size_t)(n + 1) * sizeof(bpp_finished_row));
+    return 0;
+}
+
 int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, void *stream) {
     (void)stream;
     if (!device_src || !host_dst || nbytes <= 0) return fail(BPP_E_BADARG, "bpp_fetch_to_host: NULL pointer / non-positive size");

@@ -359,6 +359,60 @@ def test_gpu_dropin_infos_read_late_are_still_the_steps_own(bpp):
         first[0]
 
 
+def test_gpu_dropin_finished_infos_through_the_native_gather(bpp, oracle):
+    """step() on 8 192 bins with the fused draw: infos.episodes() (bpp_gather_finished, one launch) and the dicts of the
+    finished bins equal the oracle's numbers of the same step; the staging cap and the legacy-checkpoint path of ADVICE r3."""
+    import torch
+    size, E = (10, 10, 10), 8192
+    pool = bpp.sequences.cut2_pool(size, 256, seed=3)
+    env = bpp.BppVecEnv(E, size, pool=pool, fresh_outputs=True)
+    ref = oracle.OracleEnv(pool, size, False, E)
+    env.reset()
+    ref.reset()
+    a = env.sample_feasible(seed=9, step=0)
+    seen = 0
+    for t in range(25):
+        a_np = a.cpu().numpy().copy()
+        obs, reward, done, infos = env.step(a, sample=(9, t + 1, a))
+        o = ref.step(a_np)
+        np.testing.assert_array_equal(done, o["done"].astype(bool))
+        np.testing.assert_array_equal(reward.numpy()[:, 0], o["reward"])
+        np.testing.assert_array_equal(a.cpu().numpy(), oracle.sample_feasible(o["mask"], 9, t + 1))
+        ep = infos.episodes()
+        d = np.flatnonzero(o["done"])
+        np.testing.assert_array_equal(ep["bins"], d)
+        np.testing.assert_array_equal(ep["r"], np.round(o["ep_ret"][d], 6))
+        np.testing.assert_array_equal(ep["l"], o["ep_len"][d])
+        np.testing.assert_array_equal(ep["ratio"], o["ratio"][d])
+        np.testing.assert_array_equal(ep["counter"], o["counter"][d])
+        for i in d[:5]:
+            assert infos[int(i)]["episode"]["r"] == round(float(o["ep_ret"][i]), 6) and infos[int(i)]["ratio"] == o["ratio"][i]
+        seen += d.size
+    assert seen > E
+    # a loop that keeps every step's reward / done views: page-locked staging stops growing at MAX_STAGING, results stay right
+    kept = []
+    with pytest.warns(RuntimeWarning, match="page-locked"):
+        for t in range(env.MAX_STAGING + 4):
+            a_np = a.cpu().numpy().copy()
+            kept.append(env.step(a, sample=(9, 100 + t, a))[1:3])
+            o = ref.step(a_np)
+            np.testing.assert_array_equal(kept[-1][0].numpy()[:, 0], o["reward"])
+            np.testing.assert_array_equal(kept[-1][1], o["done"].astype(bool))
+    assert len(env._stage_pool) == env.MAX_STAGING
+    # checkpoints: a legacy one (no format, hmax word zero, slotted `stats`) is repaired on load
+    sd = env.state_dict()
+    assert sd["format"] == 1
+    legacy = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sd.items() if k not in ("format", "ep_acc")}
+    legacy["state"][:, 11] = 0
+    legacy["stats"] = torch.zeros(4)
+    env2 = bpp.BppVecEnv(E, size, pool=pool)
+    with pytest.warns(RuntimeWarning, match="legacy checkpoint"):
+        env2.load_state_dict(legacy)
+    np.testing.assert_array_equal(env2.state_numpy()["hmax"], ref.state["hmax"])
+    np.testing.assert_array_equal(env2.state_numpy()["hmax"], env.hmap.max(1).values.cpu().numpy())
+    assert float(env2.ep_acc.abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1000), ((20, 20, 20), False, 301),
                                          ((20, 20, 10), True, 130), ((7, 13, 8), True, 97)])
 def test_gpu_fused_next_action_equals_standalone_sampler(bpp, oracle, kernel_path, size, rot, E):

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Cost of the REFERENCE-SHAPED step() (acktr/envs.py:170-193 types: obs on the device, reward CPU float32 [E,1],
-done numpy bool, lazily built infos) per lock-step, next to the tensor-native step_tensors().  The action source is a
-separate bpp_sample_feasible launch per step (a policy would stand there).  Variants: what the loop touches afterwards.
+done numpy bool, lazily built infos) per lock-step, next to the tensor-native step_tensors().
+
+Action source: `step` draws the next action inside the step kernel (sample=...: what stands where a policy would is
+then nothing but the policy); `step+sampler_launch` keeps round 3's separate bpp_sample_feasible launch per step.
+Variants: what the loop touches afterwards -- nothing; the finished bins' infos through one dict (first access pays the
+gather); ALL finished bins scanned the way main.py:159-162 scans them (a Python loop over done_indices());
+the same numbers as arrays (infos.episodes()); one running bin's info.
 
     python tools/bench_dropin_step.py [--envs 65536] [--steps 300]
 One JSON line."""
@@ -28,36 +33,65 @@ def main():
         env = bpp_amd.BppVecEnv(args.envs, size, pool=pool, fresh_outputs=fresh)
         env.reset()
         a = env.sample_feasible(seed=1, step=0)
+        host = {"async": 0.0, "wait": 0.0, "n": 0}
 
         def run(kind, n, t0):
             nonlocal a
             for t in range(t0, t0 + n):
                 if kind == "tensors":
-                    env.step_tensors(a)
-                else:
+                    env.step_tensors(a, sample=(1, t + 1, a))
+                    continue
+                if kind == "step+sampler_launch":
                     obs, rew, done, infos = env.step(a)
-                    if kind == "step+finished_infos":
-                        idx = infos.done_indices()
-                        if idx.size:
-                            infos[int(idx[0])]["episode"]["r"]
-                    elif kind == "step+running_info":
-                        infos[0]["ratio"]
-                env.sample_feasible(seed=1, step=t + 1, out=a)
+                    env.sample_feasible(seed=1, step=t + 1, out=a)
+                    continue
+                h0 = time.perf_counter()
+                env.step_async(a, sample=(1, t + 1, a))
+                h1 = time.perf_counter()
+                obs, rew, done, infos = env.step_wait()
+                h2 = time.perf_counter()
+                host["async"] += h1 - h0
+                host["wait"] += h2 - h1
+                host["n"] += 1
+                if kind == "step+one_finished_info":
+                    idx = infos.done_indices()
+                    if idx.size:
+                        infos[int(idx[0])]["episode"]["r"]
+                elif kind == "step+scan_finished_like_main_py":
+                    episode_rewards, episode_ratio = [], []
+                    for i in infos.done_indices():                      # main.py:159-162 over the finished bins
+                        if "episode" in infos[i].keys():
+                            episode_rewards.append(infos[i]["episode"]["r"])
+                            episode_ratio.append(infos[i]["ratio"])
+                elif kind == "step+episodes_arrays":
+                    ep = infos.episodes()
+                    ep["r"].sum(), ep["ratio"].sum()
+                elif kind == "step+running_info":
+                    infos[0]["ratio"]
 
-        for kind in ("tensors", "step", "step+finished_infos", "step+running_info"):
-            run(kind, 30, 0)
+        kinds = ["tensors", "step", "step+sampler_launch", "step+one_finished_info", "step+episodes_arrays", "step+running_info",
+                 "step+scan_finished_like_main_py"]
+        for kind in kinds:
+            n = args.steps if kind != "step+scan_finished_like_main_py" else max(10, args.steps // 10)
+            run(kind, 30 if n > 30 else 3, 0)
             torch.cuda.synchronize()
+            host.update(**{"async": 0.0, "wait": 0.0, "n": 0})
             t0 = time.perf_counter()
-            run(kind, args.steps, 30)
+            run(kind, n, 30)
             torch.cuda.synchronize()
-            us = (time.perf_counter() - t0) / args.steps * 1e6
-            out["%s%s_us_per_lockstep" % (kind, "_fresh_outputs" if fresh else "")] = round(us, 1)
+            us = (time.perf_counter() - t0) / n * 1e6
+            key = "%s%s_us_per_lockstep" % (kind, "_fresh_outputs" if fresh else "")
+            out[key] = round(us, 1)
+            if kind == "step":
+                out["step%s_host_us_in_step_async" % ("_fresh_outputs" if fresh else "")] = round(host["async"] / host["n"] * 1e6, 1)
+                out["step%s_host_us_in_step_wait" % ("_fresh_outputs" if fresh else "")] = round(host["wait"] / host["n"] * 1e6, 1)
         del env
         torch.cuda.empty_cache()
-    out["note"] = ("step = step kernel (also writing reward + done, 5 bytes per bin, into page-locked host memory) + separate "
-                   "action-sampling launch + stream sync; "
-                   "+finished_infos: gather and copy the finished bins' (r, l, ratio, counter); +running_info: copy counter / ratio "
-                   "of all bins (12 bytes per bin)")
+    out["note"] = ("tensors / step: ONE launch per lock-step (the step kernel draws the next action itself); step = step kernel (also "
+                   "writing reward + done, 5 bytes per bin, into page-locked host memory) + stream sync; +sampler_launch: a separate "
+                   "bpp_sample_feasible launch per step as in round 3; +one_finished_info / +episodes_arrays: bpp_gather_finished "
+                   "(one launch + sync) for the finished bins' (r, l, ratio, counter); +scan_finished_like_main_py: a Python loop "
+                   "over the ~11 % of bins that finished, two dict reads each; +running_info: counter / ratio of all bins (12 B per bin)")
     print(json.dumps(out))
 
 
