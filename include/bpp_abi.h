@@ -296,23 +296,19 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
 int bpp_wait(void *stream);
 
 /* `infos` of the bins that finished in a lock-step (main.py:159-162 reads infos[i]['episode']['r'] and infos[i]['ratio']
- * of exactly those; bench/monitor.py:64-75, bin3D.py:111).  One launch compacts the step's per-bin outputs of the bins
- * with done != 0, in ascending bin order, into rows_dev[1 ..] (device memory, capacity E + 1 rows; rows_dev[0].bin =
- * their number); then n + 1 rows are copied to rows_host (page-locked) and the stream is synchronised.  `n` is the
- * number of finished bins the caller counted in ITS copy of `done` (step_wait() has it on the host already): only what is
- * needed crosses PCIe, in one transfer.  A header count different from n means the caller's `done` belongs to another
- * step: BPP_E_BADARG.  Blocks the calling thread like bpp_fetch_to_host. */
-typedef struct bpp_finished_row {
-    double  ep_ret;   /* float64 sum of the episode's rewards in step order (Monitor's `r` before round(., 6)) */
-    double  ratio;    /* space utilisation of the bin that just finished                                     */
-    int32_t ep_len;   /* lock-steps of the episode incl. the failing one (Monitor's `l`)                      */
-    int32_t counter;  /* boxes placed                                                                         */
-    int32_t bin;      /* local bin number (header row: number of rows that follow)                            */
-    int32_t reserved;
-} bpp_finished_row;   /* 32 bytes */
+ * of exactly those; bench/monitor.py:64-75, bin3D.py:111).  `n` = the number of finished bins the caller counted in ITS
+ * copy of `done` (step_wait() has it on the host already).  One launch compacts the step's per-bin outputs of the bins
+ * with done != 0, in ascending bin order, into `dev` (device memory, BPP_FINISHED_BYTES(E) bytes) as five arrays of n
+ * entries behind a 32-byte header:
+ *     int32 count (the kernel's own count of finished bins), 28 bytes reserved;
+ *     float64 ep_ret[n] (Monitor's `r` before round(., 6)); float64 ratio[n]; int32 ep_len[n] (Monitor's `l`);
+ *     int32 counter[n] (boxes placed); int32 bin[n] (local bin numbers);
+ * then the first BPP_FINISHED_BYTES(n) bytes are copied to `host` (page-locked) and the stream is synchronised: only what
+ * is needed crosses PCIe, in one transfer, already laid out as the arrays a caller wants.  count != n (the caller's `done`
+ * belongs to another step): BPP_E_BADARG.  Blocks the calling thread like bpp_fetch_to_host. */
+#define BPP_FINISHED_BYTES(n) (32 + 28 * (int64_t)(n) + 4)      /* (+ 4: room for the 8-byte alignment of nothing -- n may be odd) */
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
-                        const int32_t *counter, int32_t E, bpp_finished_row *rows_dev, bpp_finished_row *rows_host, int32_t n,
-                        void *stream);
+                        const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream);
 
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }

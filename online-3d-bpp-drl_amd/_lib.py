@@ -17,7 +17,7 @@ LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 11
+ABI_VERSION = 11   # (bpp_gather_finished, the acc_reduce scratch and the byte-sized stream records all arrived in 11)
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 REDUCE_LANES = 1024

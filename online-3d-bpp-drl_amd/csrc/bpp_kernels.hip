@@ -1828,14 +1828,18 @@ __global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, in
 
 // bpp_gather_finished: ordered compaction of the finished bins' per-bin outputs by ONE workgroup (64 KB of `done` per
 // 65 536 bins -- a few microseconds; the transfer to the host is what the call is about).  Thread t of a round owns 16
-// consecutive bins; exclusive prefix of the per-thread counts by wave shuffles + one LDS pass over the 16 waves.
+// consecutive bins; exclusive prefix of the per-thread counts by wave shuffles + one LDS pass over the 16 waves.  Output:
+// header + five arrays of n entries (include/bpp_abi.h); entries beyond n (a caller whose count is wrong) are dropped,
+// the header tells.
 __global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
                                                                 const int32_t *ep_len, const int32_t *counter, int E,
-                                                                bpp_finished_row *rows) {
+                                                                unsigned char *out, int n) {
     static __shared__ int wave_tot[16];
     static __shared__ int wave_off[16];
     static __shared__ int total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
+    int32_t *o_len = (int32_t *)(o_ratio + n), *o_cnt = o_len + n, *o_bin = o_cnt + n;
     int base = 0;
     for (int c0 = 0; c0 < E; c0 += 1024 * 16) {
         const int e0 = c0 + t * 16;
@@ -1869,28 +1873,24 @@ __global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *d
             total = s;
         }
         __syncthreads();
-        int pos = 1 + base + wave_off[wave] + incl - cnt;     // row 0 is the header
+        int pos = base + wave_off[wave] + incl - cnt;
         while (m) {
             const int k = __ffs((int)m) - 1;
             m &= m - 1;
             const int e = e0 + k;
-            bpp_finished_row r;
-            r.ep_ret = ep_ret[e];
-            r.ratio = ratio[e];
-            r.ep_len = ep_len[e];
-            r.counter = counter[e];
-            r.bin = e;
-            r.reserved = 0;
-            rows[pos++] = r;
+            if (pos < n) {
+                o_ret[pos] = ep_ret[e];
+                o_ratio[pos] = ratio[e];
+                o_len[pos] = ep_len[e];
+                o_cnt[pos] = counter[e];
+                o_bin[pos] = e;
+            }
+            ++pos;
         }
         base += total;
         __syncthreads();
     }
-    if (t == 0) {
-        bpp_finished_row h;
-        h.ep_ret = 0.0, h.ratio = 0.0, h.ep_len = 0, h.counter = 0, h.bin = base, h.reserved = 0;
-        rows[0] = h;
-    }
+    if (t < 8) ((int32_t *)out)[t] = t == 0 ? base : 0;
 }
 
 thread_local char g_err[256];
@@ -2482,19 +2482,19 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
 }
 
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
-                        const int32_t *counter, int32_t E, bpp_finished_row *rows_dev, bpp_finished_row *rows_host, int32_t n,
-                        void *stream) {
-    if (!done || !ep_ret || !ratio || !ep_len || !counter || !rows_dev || !rows_host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+                        const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !dev || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
     if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    if (((uintptr_t)dev & 7u) || ((uintptr_t)host & 7u)) return fail(BPP_E_BADARG, "bpp_gather_finished: buffers must be 8-byte aligned");
     hipLaunchKernelGGL(compact_finished_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
-                       rows_dev);
+                       (unsigned char *)dev, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    e = hipMemcpyAsync(rows_host, rows_dev, (size_t)(n + 1) * sizeof(bpp_finished_row), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    e = hipMemcpyAsync(host, dev, (size_t)BPP_FINISHED_BYTES(n), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
     e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
-    if (rows_host[0].bin != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
+    if (*(const int32_t *)host != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
     return 0;
 }
 
@@ -2576,8 +2576,8 @@ int check_stream(const bpp_stream *s) {
 // rows the sort kernel can stage in LDS, and a cut-kernel workgroup that fits the LDS of a CU.
 struct StreamPlan {
     bool fast;
-    int maxn, cap, nsp, nslots;
-    size_t off_jobs, off_target, off_rows, off_spill, fast_bytes, legacy_bytes, cut_lds, sort_lds;
+    int maxn, cap, nsp, nslots, fb;
+    size_t off_jobs, off_target, off_rows, off_spill, off_twist, fast_bytes, legacy_bytes, cut_lds, sort_lds;
 };
 StreamPlan plan_stream(const bpp_stream *s) {
     StreamPlan p{};
@@ -2590,9 +2590,11 @@ StreamPlan plan_stream(const bpp_stream *s) {
     p.off_target = (p.off_jobs + 3 * E * 4 + 15) & ~(size_t)15;
     p.off_rows = (p.off_target + E * 4 + 15) & ~(size_t)15;
     p.off_spill = (p.off_rows + (size_t)s->depth * E * 8 + 15) & ~(size_t)15;
-    p.fast_bytes = p.off_spill + (size_t)2 * p.nsp * p.nslots * 4;
+    p.off_twist = (p.off_spill + (size_t)2 * p.nsp * p.nslots * 4 + 15) & ~(size_t)15;
+    p.fast_bytes = p.off_twist + (size_t)(p.nslots / 64) * kTwistWords * 4;     // one twist scratch per cut wave
+    p.fb = stream_field_bits(s->W, s->L, s->H);
     p.legacy_bytes = (size_t)stream_work_entries(s->W, s->L, s->H, s->bound_lo) * E * 8;
-    p.cut_lds = (size_t)stream_cut_lds_words(p.cap) * 4;
+    p.cut_lds = (size_t)stream_cut_lds_bytes(p.cap, p.fb);
     p.sort_lds = (size_t)4 * (s->pool_len + 256) * 4;
     p.fast = s->pool_len - 1 >= p.maxn && s->pool_len <= kSortMaxT && p.cut_lds <= 64 * 1024 && p.sort_lds <= 64 * 1024;
     return p;
@@ -2636,7 +2638,7 @@ int stream_refill(const bpp_stream *s, void *stream, int kmax, int urgent) {
     }
     unsigned char *base = (unsigned char *)s->work;
     const StreamWork w{(int32_t *)base, (int32_t *)(base + p.off_jobs), (int32_t *)(base + p.off_target), (int64_t *)(base + p.off_rows),
-                       (uint32_t *)(base + p.off_spill), p.cap, p.nsp, p.nslots, p.maxn, kmax, urgent};
+                       (uint32_t *)(base + p.off_spill), (uint32_t *)(base + p.off_twist), p.cap, p.nsp, p.nslots, p.maxn, p.fb, kmax, urgent};
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     const int E = s->num_envs;
@@ -2644,7 +2646,8 @@ int stream_refill(const bpp_stream *s, void *stream, int kmax, int urgent) {
                        *s, w);
     hipLaunchKernelGGL(stream_pretwist_kernel, dim3((unsigned)((E + 3) / 4 < 2048 ? (E + 3) / 4 : 2048)), dim3(256),
                        4 * kTwistWords * sizeof(uint32_t), st, *s, w);
-    hipLaunchKernelGGL(stream_cut_kernel, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+    if (p.fb == 4) hipLaunchKernelGGL(stream_cut_kernel<4>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+    else hipLaunchKernelGGL(stream_cut_kernel<8>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
     const int64_t most = ((int64_t)E * s->depth + 3) / 4;
     hipLaunchKernelGGL(stream_sort_kernel, dim3((unsigned)(most < 2048 ? most : 2048)), dim3(256), p.sort_lds, st, *s, w);
     e = hipGetLastError();

@@ -186,15 +186,21 @@ struct ArrayVals {
 //   [0, 32)        header: [0] index of the next unused output of the CURRENT state (0..624), [1] which half is current,
 //                  [2] set when the other half already holds the state that FOLLOWS the current one;
 //   [32, 1280)     two halves of 624 raw MT19937 state words;
-//   [1280, 2528)   the same two halves tempered (= the outputs, in order);
-//   [2528, 2784)   copy of the first 256 tempered words of half 0, so that a run of outputs that starts in half 1 and
-//                  continues in its successor (half 0) is contiguous in memory like one that starts in half 0.
+//   [1280, 1656)   the OUTPUTS as BYTES: the top eight bits of every tempered word -- all a draw ever looks at:
+//                  random.choice / random.randint on sides <= 255 are getrandbits(k <= 8) = output >> (32 - k) -- of half 0
+//                  (624 bytes), of half 1 (624 bytes), then a copy of the first 256 bytes of half 0, so that a run of outputs
+//                  that starts in half 1 and continues in its successor (half 0) is contiguous in memory like one that
+//                  starts in half 0.  (Round 3 kept the tempered WORDS: 2 784 words per record; a refill's readers now
+//                  fetch a quarter of the bytes and hold a quarter of the registers.)
 // The fast pipeline regenerates states in a separate, fully parallel kernel (pretwist), so a generator that runs off the
 // end of its state just changes halves, and consuming outputs is reading memory: nothing is buffered between refills.
 constexpr int kMtHalf = 624;
 constexpr int kMtPos = 0, kMtPar = 1, kMtNextOk = 2;
-constexpr int kMtRaw = 32, kMtOut = kMtRaw + 2 * kMtHalf, kMtMirror = kMtOut + 2 * kMtHalf, kMtMirrorLen = 256;
-constexpr int kMtRec = kMtMirror + kMtMirrorLen;     // 2784 words = 87 lines of 128 bytes
+constexpr int kMtRaw = 32, kMtOut8 = kMtRaw + 2 * kMtHalf, kMtMirrorLen = 256;
+constexpr int kMtOut8Bytes = 2 * kMtHalf + kMtMirrorLen;       // 1504
+constexpr int kMtRec = kMtOut8 + kMtOut8Bytes / 4;           // 1656 words = 6 624 bytes
+static_assert(kMtOut8Bytes % 4 == 0 && (kMtRec * 4) % 16 == 0, "records stay 16-byte aligned");
+__host__ __device__ inline uint8_t *mt_out8(uint32_t *rec) { return (uint8_t *)(rec + kMtOut8); }
 
 __host__ __device__ inline int stream_work_entries(int W, int L, int H, int lo) { return W * L * H / (lo * lo * lo) + 8; }
 
@@ -236,16 +242,23 @@ struct StreamWork {        // views into bpp_stream.work (see plan_stream)
                            //      kernels may be running beside the refill, the kernels must agree on one value)
     int64_t *rows;         // [D * E]: bin | episode << 32 of every row rewritten by this refill
     uint32_t *spill;       // [2 * nsp][nslots]: pending boxes beyond the LDS lists (rare)
+    uint32_t *twist;       // [cut waves][kTwistWords]: scratch of the twist a cut wave does itself (a job on its second lap; rare)
     int32_t cap, nsp, nslots, maxn;
+    int32_t fb;            // bits per field of a pending / unsorted box (stream_field_bits)
     int32_t kmax, urgent;  // kmax > 0: a bin gets at most kmax sequences per refill unless that leaves it fewer than
                            // `urgent` rows from its current episode (then as many as it takes); 0: always all depth rows
 };
-constexpr int kOutRing = 64;           // outputs a lane holds in LDS (+ kCand - 1 slots repeating the first ones, so that
-                                       // kCand consecutive outputs are consecutive slots wherever they start)
-constexpr int kOutFetch = 48;          // outputs loaded per top-up
-constexpr int kTopUpEvery = 8;         // iterations between top-ups
+constexpr int kOutRing = 64;           // output BYTES a lane holds in LDS, its own contiguous run of kRingStride bytes:
+                                       // position p of the job's output sequence at byte p % 64, the first kCand bytes
+                                       // repeated behind byte 63 so that kCand consecutive outputs are consecutive bytes
+                                       // wherever they start
 constexpr int kCand = 8;               // outputs a rejection loop looks at per iteration
-constexpr int kTwistWords = 640;       // LDS scratch of a wave-wide twist (624 used)
+constexpr int kRingStride = 76;        // 64 + 8 + a dummy word; 19 dwords per lane: an odd stride, aligned dword accesses of
+                                       // the 32 lanes of a group fall into 32 different banks
+constexpr int kRingDummy = kOutRing + kCand;   // byte offset of the lane's dummy word
+constexpr int kOutFetch = 48;          // output bytes loaded per top-up (twelve packed words)
+constexpr int kTopUpEvery = 8;         // iterations between top-ups
+constexpr int kTwistWords = 640;       // scratch of a wave-wide twist (624 used)
 constexpr int kSortMaxT = 2048;        // longest row the sort kernel stages in LDS
 constexpr int kScanThreads = 1024;
 
@@ -257,7 +270,15 @@ __host__ inline int stream_pend_cap(int maxn) {
     c = c < 16 ? 16 : (c > 80 ? 80 : c);
     return c < maxn ? c : maxn;
 }
-__host__ __device__ inline int stream_cut_lds_words(int cap) { return (2 * cap + 1 + kOutRing + kCand) * 64 + kTwistWords; }
+// A pending box is four fields of FB bits: x | y << FB | z << 2 FB | base height << 3 FB.  Bins whose sides are all below
+// 16 (every 10^3-class bin) use FB = 4: a box is 16 bits and the LDS lists are arrays of half-words -- half the LDS of the
+// round-3 kernel's lists, which together with the byte-sized outputs takes a cut wave from 31 KB of LDS to 11 KB (the step
+// kernel's workgroups need 18.9 KB each and the two kernels run side by side).  FB = 8 for anything larger.
+__host__ __device__ inline int stream_field_bits(int W, int L, int H) { return (W < 16 && L < 16 && H < 16) ? 4 : 8; }
+// bytes of LDS of a cut wave: the two lists + the dummy entry, the rings
+__host__ __device__ inline int stream_cut_lds_bytes(int cap, int fb) {
+    return ((2 * cap + 1) * 64 * (fb == 4 ? 2 : 4) + 15) / 16 * 16 + 64 * kRingStride;
+}
 
 __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(bpp_stream s, StreamWork w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * [waves][4] counters
@@ -301,14 +322,28 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(bpp_stream s,
     for (int k = 0; k < nr; ++k) w.rows[at + k] = (int64_t)(uint32_t)e | ((int64_t)(first + k) << 32);
 }
 
-// The whole wave computes the state that follows half `par` of a record into the other half: raw words, outputs and,
-// for half 0, the mirror (tw: LDS scratch).  Word k needs the OLD words k and k+1 and word k+397 (old for k < 227, else
-// the NEW word k-227); walking k in rounds of 64 consecutive words with all reads of a round before its writes gives
-// every lane exactly those values (word 623 reads the new word 0, as the serial loop does).
+// The whole wave computes the state that follows half `par` of a record into the other half: raw words, output bytes
+// and, for half 0, the mirror (tw: scratch of kTwistWords words).  Word k needs the OLD words k and k+1 and word k+397
+// (old for k < 227, else the NEW word k-227); walking k in rounds of 64 consecutive words with all reads of a round before
+// its writes gives every lane exactly those values (word 623 reads the new word 0, as the serial loop does).
+// GLOBAL_TW: the scratch is global memory (the cut kernel, whose LDS is the pending lists and rings and nothing else):
+// other lanes' words are then ordered by a workgroup-scope release / acquire around the wave barrier instead of the
+// wavefront-scope one that suffices for LDS.
+template <bool GLOBAL_TW>
+__device__ __forceinline__ void twist_sync() {
+    if constexpr (GLOBAL_TW) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        wave_sync();
+    }
+}
+template <bool GLOBAL_TW>
 __device__ __forceinline__ void stream_wave_twist(uint32_t *rec, uint32_t par, uint32_t *tw, int lane) {
     const uint32_t *src = rec + kMtRaw + par * kMtHalf;
     for (int k = lane; k < 624; k += 64) tw[k] = src[k];
-    wave_sync();
+    twist_sync<GLOBAL_TW>();
     for (int k0 = 0; k0 < 624; k0 += 64) {
         const int k = k0 + lane;
         uint32_t a = 0, b = 0, c = 0;
@@ -317,19 +352,21 @@ __device__ __forceinline__ void stream_wave_twist(uint32_t *rec, uint32_t par, u
             b = tw[k + 1 < 624 ? k + 1 : 0];
             c = tw[k + 397 < 624 ? k + 397 : k - 227];
         }
-        wave_sync();
+        twist_sync<GLOBAL_TW>();
         if (k < 624) {
             const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
             tw[k] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        wave_sync();
+        twist_sync<GLOBAL_TW>();
     }
     const uint32_t to = par ^ 1u;
+    uint8_t *out8 = mt_out8(rec);
     for (int k = lane; k < 624; k += 64) {
-        const uint32_t y = tw[k], t = mt_temper(y);
+        const uint32_t y = tw[k];
+        const uint8_t t = (uint8_t)(mt_temper(y) >> 24);
         rec[kMtRaw + to * kMtHalf + k] = y;
-        rec[kMtOut + to * kMtHalf + k] = t;
-        if (to == 0u && k < kMtMirrorLen) rec[kMtMirror + k] = t;
+        out8[to * kMtHalf + k] = t;
+        if (to == 0u && k < kMtMirrorLen) out8[2 * kMtHalf + k] = t;
     }
 }
 
@@ -346,29 +383,40 @@ __global__ __launch_bounds__(256) void stream_pretwist_kernel(bpp_stream s, Stre
         if (rec[kMtNextOk] == 0u) {
             const uint32_t par = rec[kMtPar];
             wave_sync();
-            stream_wave_twist(rec, par, scratch[wave], lane);
+            stream_wave_twist<false>(rec, par, scratch[wave], lane);
             if (lane == 0) rec[kMtNextOk] = 1u;
         }
         wave_sync();
     }
 }
 
+// The LDS part of a lane's two pending lists (+ one dummy entry): entry w of this lane at index w * 64 of an array of
+// half-words (FB = 4) or words (FB = 8).
+template <int FB>
+struct ListCol {
+    using T = typename std::conditional<FB == 4, uint16_t, uint32_t>::type;
+    T *p;               // &array[lane]
+    __device__ __forceinline__ uint32_t get(uint32_t w) const { return (uint32_t)p[w * 64]; }
+    __device__ __forceinline__ void set(uint32_t w, uint32_t v) const { p[w * 64] = (T)v; }
+};
+
 // the pending lists of one lane with their continuation in global memory: list r (0 / 1), entry i
+template <int FB>
 struct PendLists {
-    uint32_t *lds;      // &lds[lane]: word w of this lane at lds[w * 64]
+    ListCol<FB> lds;
     uint32_t *spill;    // &spill[slot]: entry k of list r beyond the LDS part at spill[(r * nsp + k) * nslots]
     int cap, nsp;
     size_t nslots;
     __device__ __forceinline__ uint32_t get(int r, int i) const {
-        return i < cap ? lds[(r * cap + i) * 64] : spill[(size_t)(r * nsp + i - cap) * nslots];
+        return i < cap ? lds.get((uint32_t)(r * cap + i)) : spill[(size_t)(r * nsp + i - cap) * nslots];
     }
     __device__ __forceinline__ void set(int r, int i, uint32_t v) const {
-        if (i < cap) lds[(r * cap + i) * 64] = v;
+        if (i < cap) lds.set((uint32_t)(r * cap + i), v);
         else spill[(size_t)(r * nsp + i - cap) * nslots] = v;
     }
 };
 
-// State of one lane's list walk.  A pending box is x | y << 8 | z << 16 | base height << 24 (its top is base + z).
+// State of one lane's list walk.  A pending box is x | y << FB | z << 2 FB | base height << 3 FB (its top is base + z).
 struct CutLane {
     uint32_t box, v;        // box being visited; side being cut (valid in state 1)
     int st, f;              // 0: the next output chooses the side (random.choice), 1: it is the cut position (randint)
@@ -379,18 +427,28 @@ struct CutLane {
     int used;               // outputs consumed since the job started
 };
 
+// The kCand output bytes that follow position `from` of the lane's ring, as two packed words (byte j of the run in bits
+// 8 j .. 8 j + 7 of lo for j < 4, of hi for j >= 4): three aligned dword reads (the repeated first bytes make the run
+// contiguous across the end of the ring) and two byte alignments.
+__device__ __forceinline__ void ring_run(const uint8_t *ringb, int from, uint32_t &lo, uint32_t &hi) {
+    const uint32_t pos = (uint32_t)from & (kOutRing - 1);
+    const uint32_t *pw = (const uint32_t *)(ringb + (pos & ~3u));
+    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, pos & 3u);
+}
+
 // `getrandbits(k) until below lim` on the (at most kCand) outputs the lane holds from position `from` of its ring:
-// index of the first accepted output and its value; kCand when none is accepted.  The compares are independent of each
-// other -- this is where a visit's serial chain of draws becomes work done side by side.
-__device__ __forceinline__ void first_below(const uint32_t *ring, int from, uint32_t shift, uint32_t lim, int &first, uint32_t &x) {
-    uint32_t u[kCand];
-#pragma unroll
-    for (int j = 0; j < kCand; ++j) u[j] = ring[((from + j) & (kOutRing - 1)) * 64];
+// index of the first accepted output and its value; kCand when none is accepted.  k = bit_length(lim) <= 8: the draw is
+// the top k bits of the output's byte.
+__device__ __forceinline__ void first_below(const uint8_t *ringb, int from, uint32_t k, uint32_t lim, int &first, uint32_t &x) {
+    uint32_t lo, hi;
+    ring_run(ringb, from, lo, hi);
     first = kCand;
     x = 0;
 #pragma unroll
     for (int j = kCand - 1; j >= 0; --j) {
-        const uint32_t xj = u[j] >> shift;
+        const uint32_t xj = (((j < 4 ? lo : hi) >> (8 * (j & 3))) & 255u) >> (8u - k);
         const bool a = xj < lim;
         first = a ? j : first;
         x = a ? xj : x;
@@ -408,34 +466,44 @@ __device__ __forceinline__ uint32_t m_sel(uint32_t m, uint32_t a, uint32_t b) { 
 // output wins.  Every output becomes a key -- position << 8 | value when accepted, above 0xffff when not -- and the
 // smallest key is the answer; the keys are independent of each other, which is what turns a visit's serial chain of
 // draws into work done side by side.  Returns the key: position = key >> 8 (>= 256: none accepted), value = key & 255.
-__device__ __forceinline__ uint32_t first_below_key(const uint32_t *ring, int from, uint32_t shift, uint32_t lim) {
-    const uint32_t *p = ring + (from & (kOutRing - 1)) * 64;
+// The draw of output j is the top k bits of its byte: both packed words are shifted right by 8 - k once, after which
+// the draw sits in bits 8 j .. 8 j + k - 1 -- one bit-field extract per output (what is left of the neighbour byte above
+// it lies outside the field).
+__device__ __forceinline__ uint32_t first_below_key(const uint8_t *ringb, int from, uint32_t k, uint32_t lim) {
+    uint32_t lo, hi;
+    ring_run(ringb, from, lo, hi);
+    lo >>= 8u - k;
+    hi >>= 8u - k;
     const uint32_t lim1 = lim - 1u;
-    uint32_t k[kCand];
+    uint32_t key[kCand];
 #pragma unroll
     for (int j = 0; j < kCand; ++j) {
-        const uint32_t xj = p[j * 64] >> shift;
-        k[j] = (((lim1 - xj) >> 31) << 16) | (xj | ((uint32_t)j << 8));
+        const uint32_t xj = __builtin_amdgcn_ubfe(j < 4 ? lo : hi, 8u * (uint32_t)(j & 3), k);
+        key[j] = (((lim1 - xj) >> 31) << 16) | (xj | ((uint32_t)j << 8));
     }
     static_assert(kCand == 8, "min tree below is written for eight candidates");
-    return min(min(min(k[0], k[1]), min(k[2], k[3])), min(min(k[4], k[5]), min(k[6], k[7])));
+    return min(min(min(key[0], key[1]), min(key[2], key[3])), min(min(key[4], key[5]), min(key[6], key[7])));
 }
+__device__ __forceinline__ uint32_t bit_length(uint32_t v) { return 32u - (uint32_t)__clz((int)v); }   // v > 0
 
 // One visit for a lane whose lists are certain to stay inside LDS (tail_a + 2 <= cap, tail_b + 1 <= cap): the statement
 // of cut_visit_general below without divergent branches and without selects on condition codes.  `act` is the lane's
 // all-ones / zero activity mask; returns the mask "sequence complete".
-__device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int cap, const uint32_t *ring, int filled, uint32_t act,
+template <int FB>
+__device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, const ListCol<FB> col, int cap, const uint8_t *ringb, int filled, uint32_t act,
                                                   uint32_t lo, uint32_t hi) {
+    constexpr uint32_t FM = (1u << FB) - 1u;
     const uint32_t dummy = 2u * (uint32_t)cap;
     const uint32_t abase = (uint32_t)cap & (0u - (uint32_t)c.side), bbase = (uint32_t)cap - abase;
     const uint32_t box = c.box;
-    const uint32_t bx = box & 255u, by = (box >> 8) & 255u, bz = (box >> 16) & 255u;
+    const uint32_t bx = box & FM, by = (box >> FB) & FM, bz = (box >> (2 * FB)) & FM;
     const uint32_t mfx = m_lt(hi, bx), mfy = m_lt(hi, by), mfz = m_lt(hi, bz);          // :60-66
     const uint32_t nf = 0u - (mfx + mfy + mfz);
     const uint32_t monly = m_eq(nf, 1u);
     const uint32_t mst0 = (uint32_t)c.st - 1u;                                          // st is 0 or 1
-    // random.choice(flags) (:68), or random.randint(1, v) (:73 / :83 / :93) for a lane that chose its side earlier
-    const uint32_t key1 = first_below_key(ring, c.used, m_sel(mst0, 30u - monly, (uint32_t)__clz((int)c.v)), m_sel(mst0, nf, c.v));
+    // random.choice(flags) (:68) -- getrandbits(1) for one long side, getrandbits(2) for two or three --, or
+    // random.randint(1, v) (:73 / :83 / :93) for a lane that chose its side earlier
+    const uint32_t key1 = first_below_key(ringb, c.used, m_sel(mst0, 2u + monly, bit_length(c.v)), m_sel(mst0, nf, c.v));
     const uint32_t have1 = (uint32_t)min(filled - c.used, kCand);
     const uint32_t first1 = key1 >> 8, x1 = key1 & 255u;
     const uint32_t mfound1 = m_lt(first1, have1) & act;
@@ -445,9 +513,9 @@ __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int
     const uint32_t f1 = 2u + (mfx & mfy);                                               // second long side
     const uint32_t fnew = m_sel(m_lt(x1, 1u), f0, m_sel(m_eq(x1, 1u), f1, 2u));
     const uint32_t f = m_sel(mchoose, fnew, (uint32_t)c.f);
-    const uint32_t v = m_sel(mchoose, (box >> (8u * fnew)) & 255u, c.v);
+    const uint32_t v = m_sel(mchoose, (box >> ((uint32_t)FB * fnew)) & FM, c.v);
     // the cut position for a side chosen just now
-    const uint32_t key2 = first_below_key(ring, c.used, (uint32_t)__clz((int)v), v);
+    const uint32_t key2 = first_below_key(ringb, c.used, bit_length(v), v);
     const uint32_t have2 = (uint32_t)min(filled - c.used, kCand);
     const uint32_t first2 = key2 >> 8, x2 = key2 & 255u;
     const uint32_t mfound2 = m_lt(first2, have2) & mchoose;
@@ -457,10 +525,10 @@ __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int
     const uint32_t mgood = ~(m_lt(r, lo) | m_lt(v - r, lo));                            // :74, :84, :94
     const uint32_t msplit = mfin & mgood, mfail = mfin & ~mgood;
     const uint32_t mf2 = m_eq(f, 2u);
-    const uint32_t sh = 8u * f, p1 = m_sel(mf2, v - r, r), p2 = v - p1;
-    const uint32_t rest = box & ~(255u << sh);
+    const uint32_t sh = (uint32_t)FB * f, p1 = m_sel(mf2, v - r, r), p2 = v - p1;
+    const uint32_t rest = box & ~(FM << sh);
     const uint32_t c1 = rest | (p1 << sh);
-    const uint32_t c2 = (rest | (p2 << sh)) + ((p1 << 24) & mf2);                       // :97-98: the upper part starts at high - r
+    const uint32_t c2 = (rest | (p2 << sh)) + ((p1 << (3 * FB)) & mf2);                 // :97-98: the upper part starts at high - r
     const uint32_t me1 = msplit & monly & ~m_lt(hi, p1), me2 = msplit & monly & ~m_lt(hi, p2);   // is_valid, :110-115
     const uint32_t mq1 = msplit & ~me1, mq2 = msplit & ~me2;
     uint32_t nv = (uint32_t)c.nv, tail_a = (uint32_t)c.tail_a, tail_b = (uint32_t)c.tail_b, i = (uint32_t)c.i;
@@ -468,23 +536,23 @@ __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int
     nv -= me1;
     if (me2) c.row[nv] = c2;
     nv -= me2;
-    col[m_sel(mfail, bbase + tail_b, dummy) * 64] = box;          // stays in invalid_box for the next pass
+    col.set(m_sel(mfail, bbase + tail_b, dummy), box);            // stays in invalid_box for the next pass
     tail_b -= mfail;
-    col[m_sel(mq1, abase + tail_a, dummy) * 64] = c1;             // appended: visited later in this pass
+    col.set(m_sel(mq1, abase + tail_a, dummy), c1);               // appended: visited later in this pass
     tail_a -= mq1;
-    col[m_sel(mq2, abase + tail_a, dummy) * 64] = c2;
+    col.set(m_sel(mq2, abase + tail_a, dummy), c2);
     tail_a -= mq2;
     c.st = (int)(((uint32_t)c.st | (mchoose & 1u)) & ~mfin);
     c.f = (int)f;
     c.v = v;
     i -= mfin;
     // the two entries after the visited box (the first is skipped after a split, :124) and the head of the survivors
-    const uint32_t n1 = col[(abase + min(i, (uint32_t)cap - 1u)) * 64], n2 = col[(abase + min(i + 1u, (uint32_t)cap - 1u)) * 64];
+    const uint32_t n1 = col.get(abase + min(i, (uint32_t)cap - 1u)), n2 = col.get(abase + min(i + 1u, (uint32_t)cap - 1u));
     const uint32_t mskip = msplit & m_lt(i, tail_a);
-    col[m_sel(mskip, bbase + tail_b, dummy) * 64] = n1;
+    col.set(m_sel(mskip, bbase + tail_b, dummy), n1);
     tail_b -= mskip;
     i -= mskip;
-    const uint32_t b0 = col[bbase * 64];
+    const uint32_t b0 = col.get(bbase);
     const uint32_t mpass = mfin & ~m_lt(i, tail_a);               // end of the `for`: next pass over the survivors, or done
     const uint32_t mdone = mpass & m_eq(tail_b, 0u);
     c.box = m_sel(mfin, m_sel(mpass, b0, m_sel(mskip, n2, n1)), box);
@@ -502,9 +570,11 @@ __device__ __forceinline__ uint32_t cut_visit_lds(CutLane &c, uint32_t *col, int
 // cut_visit_lds above is checked against: a wave runs it whenever one of its lanes' lists may leave LDS.
 // (`f == 0 ? v <= lo : v < lo`, :71 / :81 / :91, cannot hold: the side was chosen because it exceeds hi, and bpp_stream
 // requires hi >= 2 lo - 1 >= lo; cut2_generate keeps the test.)
-__device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &pend, const uint32_t *ring, int filled, uint32_t lo,
+template <int FB>
+__device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists<FB> &pend, const uint8_t *ringb, int filled, uint32_t lo,
                                                   uint32_t hi) {
-    const uint32_t bx = c.box & 255u, by = (c.box >> 8) & 255u, bz = (c.box >> 16) & 255u;
+    constexpr uint32_t FM = (1u << FB) - 1u;
+    const uint32_t bx = c.box & FM, by = (c.box >> FB) & FM, bz = (c.box >> (2 * FB)) & FM;
     const bool fx = bx > hi, fy = by > hi, fz = bz > hi;                    // :60-66
     const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
     const bool st0 = c.st == 0;
@@ -512,7 +582,7 @@ __device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &p
     // or, for a lane that chose its side earlier, random.randint(1, v) (:73 / :83 / :93) = 1 + (getrandbits(bit_length(v)) until < v)
     int first1, first2;
     uint32_t x1, x2;
-    first_below(ring, c.used, st0 ? (nf == 1u ? 31u : 30u) : (uint32_t)__clz((int)c.v), st0 ? nf : c.v, first1, x1);
+    first_below(ringb, c.used, st0 ? (nf == 1u ? 1u : 2u) : bit_length(c.v), st0 ? nf : c.v, first1, x1);
     const int have1 = min(filled - c.used, kCand);
     const bool found1 = first1 < have1;
     c.used += found1 ? first1 + 1 : have1;
@@ -523,7 +593,7 @@ __device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &p
         c.st = 1;
     }
     // second one: the cut position for a side chosen just now
-    first_below(ring, c.used, (uint32_t)__clz((int)c.v), c.v, first2, x2);
+    first_below(ringb, c.used, bit_length(c.v), c.v, first2, x2);
     const int have2 = min(filled - c.used, kCand);
     const bool found2 = choose && first2 < have2;
     if (choose) c.used += found2 ? first2 + 1 : have2;
@@ -534,10 +604,10 @@ __device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &p
     if (!split) {
         pend.set(c.side ^ 1, c.tail_b++, c.box);                              // stays in invalid_box for the next pass
     } else {
-        const uint32_t sh = 8u * (uint32_t)c.f, p1 = c.f == 2 ? c.v - r : r, p2 = c.v - p1;
-        const uint32_t rest = c.box & ~(255u << sh);
+        const uint32_t sh = (uint32_t)FB * (uint32_t)c.f, p1 = c.f == 2 ? c.v - r : r, p2 = c.v - p1;
+        const uint32_t rest = c.box & ~(FM << sh);
         const uint32_t c1 = rest | (p1 << sh);
-        const uint32_t c2 = (rest | (p2 << sh)) + (c.f == 2 ? p1 << 24 : 0u);   // :97-98: the upper part starts at high - r
+        const uint32_t c2 = (rest | (p2 << sh)) + (c.f == 2 ? p1 << (3 * FB) : 0u);   // :97-98: the upper part starts at high - r
         // is_valid (:110-115): the untouched sides are within bounds iff the cut side was the only long one
         if (nf == 1u && p1 <= hi) c.row[c.nv++] = c1;
         else pend.set(c.side, c.tail_a++, c1);                                // appended: visited later in this pass
@@ -562,9 +632,9 @@ __device__ __forceinline__ bool cut_visit_general(CutLane &c, const PendLists &p
     return finished;
 }
 
+template <int FB>
 __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *lds = (uint32_t *)smem;
     const int lane = threadIdx.x;
     const int E = s.num_envs, T = s.pool_len, D = s.depth, cap = w.cap;
     const uint32_t lo = (uint32_t)s.bound_lo, hi = (uint32_t)s.bound_hi;
@@ -584,10 +654,11 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     const bool job = j < n;
     const int e = job ? w.jobs[(size_t)bucket * E + j] : 0;
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
-    uint32_t *col = lds + lane;                                     // word w of this lane at col[w * 64]
-    uint32_t *ring = col + (size_t)(2 * cap + 1) * 64;              // outputs: position p (counted from the job's start) at ring[(p % 64) * 64]
-    uint32_t *tw = lds + (size_t)(2 * cap + 1 + kOutRing + kCand) * 64;   // twist scratch of the wave
-    const PendLists pend{col, w.spill + (size_t)blockIdx.x * 64 + lane, cap, w.nsp, (size_t)w.nslots};
+    const ListCol<FB> col{(typename ListCol<FB>::T *)smem + lane};      // entry w of this lane at index w * 64
+    // outputs: byte p % 64 of this lane's run holds output p (counted from the job's start)
+    uint8_t *ringb = smem + ((size_t)(2 * cap + 1) * 64 * sizeof(typename ListCol<FB>::T) + 15) / 16 * 16 + (size_t)lane * kRingStride;
+    uint32_t *tw = w.twist + (size_t)blockIdx.x * kTwistWords;        // twist scratch of the wave (global: the path is rare)
+    const PendLists<FB> pend{col, w.spill + (size_t)blockIdx.x * 64 + lane, cap, w.nsp, (size_t)w.nslots};
 
     int g = 0, need = 0, base = 0;                                   // base: index in the current state of the job's first output
     uint32_t par = 0, next_ok = 0;
@@ -600,15 +671,15 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     }
     bool active = job && need > 0;
     const bool ran = active;
-    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << FB) | ((uint32_t)s.H << (2 * FB));
     CutLane c{whole, 1u, 0, 0, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T, 0};
-    if (active) col[0] = whole;
-    int filled = 0;                                                  // outputs put into the ring since the job started
+    if (active) col.set(0u, whole);
+    int filled = 0;                                                  // outputs put into the ring since the job started (a multiple of 4)
 
-    // The next kOutFetch outputs after `filled`, loaded one top-up ahead.  Outputs of the current state and of its
-    // successor are contiguous in the record (mirror); the successor is there (pretwist kernel) -- except for a job on
-    // its second lap, for which the wave makes it now.
-    uint32_t pre[kOutFetch];
+    // The next kOutFetch output bytes after `filled`, loaded one top-up ahead as twelve packed words.  Outputs of the
+    // current state and of its successor are contiguous in the record (mirror); the successor is there (pretwist kernel)
+    // -- except for a job on its second lap, for which the wave makes it now.
+    uint32_t pre[kOutFetch / 4];
     auto fetch = [&]() {
         uint64_t m = __ballot(active && base + filled + kOutFetch > kMtHalf && !next_ok);
         while (m) {                                   // wave-uniform, rare: one bin at a time, all lanes help
@@ -616,23 +687,29 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
             m &= m - 1;
             const int el = (int)__builtin_amdgcn_readlane(e, l);
             const uint32_t pl = __builtin_amdgcn_readlane(par, l);
-            wave_sync();
-            stream_wave_twist(s.mt + (size_t)el * kMtRec, pl, tw, lane);
-            wave_sync();
+            twist_sync<true>();
+            stream_wave_twist<true>(s.mt + (size_t)el * kMtRec, pl, tw, lane);
+            twist_sync<true>();                          // the new outputs are read by lane l's fetch right below
             if (lane == l) next_ok = 1u;
         }
-        const uint32_t *p = rec + kMtOut + par * kMtHalf + base + filled;     // in-bounds for every lane, read or not
+        // in-bounds for every lane, read or not: thirteen aligned words around the 48 bytes, shifted into place
+        const uint8_t *p8 = mt_out8(rec) + par * kMtHalf + base + filled;
+        const uint32_t off = (uint32_t)((uintptr_t)p8 & 3u);
+        const uint32_t *pw = (const uint32_t *)(p8 - off);
+        uint32_t raw[kOutFetch / 4 + 1];
 #pragma unroll
-        for (int q = 0; q < kOutFetch; ++q) pre[q] = p[q];
+        for (int q = 0; q <= kOutFetch / 4; ++q) raw[q] = pw[q];
+#pragma unroll
+        for (int q = 0; q < kOutFetch / 4; ++q) pre[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], off);
     };
     auto top_up = [&]() {
         const int room = kOutRing - (filled - c.used);
-        const int put = active ? min(kOutFetch, room) : 0;
+        const int put = active ? (min(kOutFetch, room) & ~3) : 0;     // whole words: `filled` stays a multiple of 4
 #pragma unroll
-        for (int q = 0; q < kOutFetch; ++q) {
-            const uint32_t slot = (uint32_t)(filled + q) & (kOutRing - 1), mput = m_lt((uint32_t)q, (uint32_t)put);
-            ring[m_sel(mput, slot, kOutRing + kCand - 1) * 64] = pre[q];                        // (else: the dummy word, below)
-            ring[m_sel(mput & m_lt(slot, kCand - 1), slot + kOutRing, kOutRing + kCand - 1) * 64] = pre[q];   // repeated first slots
+        for (int q = 0; q < kOutFetch / 4; ++q) {
+            const uint32_t slot = (uint32_t)(filled + 4 * q) & (kOutRing - 1), mput = m_lt((uint32_t)(4 * q), (uint32_t)put);
+            *(uint32_t *)(ringb + m_sel(mput, slot, (uint32_t)kRingDummy)) = pre[q];                        // (else: the dummy word)
+            *(uint32_t *)(ringb + m_sel(mput & m_lt(slot, (uint32_t)kCand), slot + kOutRing, (uint32_t)kRingDummy)) = pre[q];   // repeated first bytes
         }
         filled += put;
         if (active && base + c.used >= kMtHalf) {     // the lane now draws from the successor: it becomes the current state
@@ -650,9 +727,9 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
         }
         bool finished;
         if (__ballot(active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap))) {   // wave-uniform: a list may leave LDS
-            finished = active ? cut_visit_general(c, pend, ring, filled, lo, hi) : false;
+            finished = active ? cut_visit_general<FB>(c, pend, ringb, filled, lo, hi) : false;
         } else {
-            finished = cut_visit_lds(c, col, cap, ring, filled, active ? ~0u : 0u, lo, hi) != 0u;
+            finished = cut_visit_lds<FB>(c, col, cap, ringb, filled, active ? ~0u : 0u, lo, hi) != 0u;
         }
         if (finished) {
             c.row[T - 1] = (uint32_t)c.nv;            // length for the sort kernel (which restores the terminator)
@@ -688,6 +765,11 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
 // most) never touch LDS: a lane holds one box, its place is the number of boxes with a lower base plus the number of
 // equal ones in lower lanes, counted with one ballot per distinct base height; the next row's boxes are loaded before
 // the current row is ranked.  Longer rows are staged in LDS and ranked chunk by chunk.
+// An unsorted box as the cut kernel leaves it (fields of w.fb bits) -> x | y << 8 | z << 16 | base height << 24.
+__device__ __forceinline__ uint32_t cut_box_bytes(uint32_t v, int fb) {
+    return fb == 8 ? v : ((v & 15u) | ((v & 0xf0u) << 4) | ((v & 0xf00u) << 8) | ((v & 0xf000u) << 12));
+}
+
 __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWork w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -703,8 +785,9 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
         const int64_t id = w.rows[k];
         return (uint32_t *)s.ring + ((size_t)((int)(id >> 32) % D) * E + (int)(uint32_t)id) * T;
     };
+    const int fb = w.fb;
     uint32_t *row = row_of(q);
-    uint32_t mine = lane < T - 1 ? row[lane] : 0u;    // this lane's box if the row is short, and the row's length
+    uint32_t mine = lane < T - 1 ? cut_box_bytes(row[lane], fb) : 0u;    // this lane's box if the row is short, and the row's length
     int nv = (int)row[T - 1];
     for (;;) {
         const int qn = q + stride;
@@ -713,7 +796,7 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
         int nvn = 0;
         if (qn < nrows) {                             // next row: loads in flight while this one is ranked
             rown = row_of(qn);
-            minen = lane < T - 1 ? rown[lane] : 0u;
+            minen = lane < T - 1 ? cut_box_bytes(rown[lane], fb) : 0u;
             nvn = (int)rown[T - 1];
         }
         if (nv <= 64) {
@@ -732,7 +815,7 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
         } else {
             wave_sync();
             for (int k = lane; k < 256; k += 64) lvl[k] = 0;
-            for (int k = lane; k < nv; k += 64) ent[k] = row[k];
+            for (int k = lane; k < nv; k += 64) ent[k] = cut_box_bytes(row[k], fb);
             wave_sync();
             for (int k = lane; k < nv; k += 64) atomicAdd(&lvl[ent[k] >> 24], 1);
             wave_sync();
@@ -855,9 +938,10 @@ struct BufferedMT {
                 if (k < 624) {
                     const uint32_t y = (cur[q] & 0x80000000u) | (cur[q + 1] & 0x7fffffffu);
                     const uint32_t nw = far[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                    mt[k] = nw;                          // and its output, for the fast pipeline's readers
-                    rec[kMtOut + par * kMtHalf + k] = mt_temper(nw);
-                    if (par == 0u && k < kMtMirrorLen) rec[kMtMirror + k] = mt_temper(nw);
+                    mt[k] = nw;                          // and its output byte, for the fast pipeline's readers
+                    const uint8_t tb = (uint8_t)(mt_temper(nw) >> 24);
+                    mt_out8(rec)[par * kMtHalf + k] = tb;
+                    if (par == 0u && k < kMtMirrorLen) mt_out8(rec)[2 * kMtHalf + k] = tb;
                 }
             }
         }

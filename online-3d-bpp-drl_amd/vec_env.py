@@ -152,8 +152,11 @@ class LazyInfos(object):
                 # ONE native call (bpp_gather_finished): a launch compacts the finished bins' (r, ratio, l, counter, bin) rows on
                 # the device in bin order, one copy brings exactly those rows over
                 n = int(np.count_nonzero(self._done_mask()))
-                rows = env._gather_finished(r, n) if n else np.zeros((0,), env.FIN_ROW)
-                self._fin = (rows["bin"].astype(np.int64), np.stack([rows["ep_ret"], rows["ratio"]]), np.stack([rows["ep_len"], rows["counter"]]))
+                if n:
+                    bins, ret, ratio, ln, cnt = env._gather_finished(r, n)
+                else:
+                    bins, ret, ratio, ln, cnt = (np.zeros(0, "<i4"), np.zeros(0), np.zeros(0), np.zeros(0, "<i4"), np.zeros(0, "<i4"))
+                self._fin = (bins, (ret, ratio), (ln, cnt))
                 return self._fin
             idx = np.flatnonzero(self._done_mask())
             if idx.size and torch.is_tensor(r.ep_ret):
@@ -168,7 +171,7 @@ class LazyInfos(object):
 
     def episodes(self):
         """The episodes that finished in this step as arrays -- what main.py:159-162 collects one dict at a time:
-        {'bins': int64 [n], 'r': float64 [n] (rounded like Monitor's), 'l': int32 [n], 'ratio': float64 [n], 'counter': int32 [n]}."""
+        {'bins': int [n], 'r': float64 [n] (rounded like Monitor's), 'l': int32 [n], 'ratio': float64 [n], 'counter': int32 [n]}."""
         idx, f64, i32 = self._finished()
         return {"bins": idx, "r": np.round(f64[0], 6), "l": i32[0], "ratio": f64[1], "counter": i32[1]}
 
@@ -186,9 +189,9 @@ class LazyInfos(object):
         if self._done_mask()[i]:
             idx, f64, i32 = self._finished()
             k = int(np.searchsorted(idx, i))
-            return {"counter": int(i32[1, k]), "ratio": np.float64(f64[1, k]),
+            return {"counter": int(i32[1][k]), "ratio": np.float64(f64[1][k]),
                     "mask": np.ones(shape=self._env.act_len),                  # bin3D.py:111
-                    "episode": {"r": round(float(f64[0, k]), 6), "l": int(i32[0, k]),
+                    "episode": {"r": round(float(f64[0][k]), 6), "l": int(i32[0][k]),
                                 "t": round(self._t - self._env._tstart, 6)}}   # bench/monitor.py:64
         counter, ratio = self._running()
         return {"counter": int(counter[i]), "ratio": np.float64(ratio[i])}
@@ -456,25 +459,25 @@ class BppVecEnv(object):
         pool.append((t, a))
         return a
 
-    FIN_ROW = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("bin", "<i4"),
-                        ("reserved", "<i4")])   # bpp_finished_row
-
     def _gather_finished(self, res, n):
-        """The `n` finished bins of step result `res` as bpp_finished_row records in ascending bin order, through
-        bpp_gather_finished: one compaction launch, ONE device-to-host copy of n + 1 rows, stream synchronise.  The device and
-        page-locked staging areas ([E + 1] rows each) are allocated on first use."""
+        """(bins int32 [n], ep_ret f64 [n], ratio f64 [n], ep_len int32 [n], counter int32 [n]) of the `n` finished bins of
+        step result `res`, ascending bin order, through bpp_gather_finished: one compaction launch, ONE device-to-host copy
+        of 32 + 28 n bytes laid out as those arrays, stream synchronise.  The device and page-locked staging areas are
+        allocated on first use; what is returned are views of ONE private copy of the transferred bytes."""
         st = getattr(self, "_fin_stage", None)
         if st is None:
-            nb = (self.E + 1) * self.FIN_ROW.itemsize
+            nb = (32 + 28 * self.E + 4 + 7) // 8 * 8
             t = torch.empty((nb,), dtype=torch.uint8).pin_memory()
-            st = self._fin_stage = (t, t.numpy().view(self.FIN_ROW), torch.empty((nb,), dtype=torch.uint8, device=self.device))
-        _, hrows, drows = st
+            st = self._fin_stage = (t, t.numpy(), torch.empty((nb,), dtype=torch.uint8, device=self.device))
+        _, host, dev = st
         base, lay = res._flat.data_ptr(), res._layout
         self._on_device()
         _lib.check(self.lib.bpp_gather_finished(base + lay["done"][0], base + lay["ep_ret"][0], base + lay["ratio"][0],
-                                                base + lay["ep_len"][0], base + lay["counter"][0], self.E, drows.data_ptr(),
-                                                hrows.ctypes.data, int(n), self._stream_ptr()))
-        return hrows[1:n + 1].copy()
+                                                base + lay["ep_len"][0], base + lay["counter"][0], self.E, dev.data_ptr(),
+                                                host.ctypes.data, int(n), self._stream_ptr()))
+        buf = host[32:32 + 28 * n].copy()
+        return (buf[24 * n:28 * n].view("<i4"), buf[:8 * n].view("<f8"), buf[8 * n:16 * n].view("<f8"),
+                buf[16 * n:20 * n].view("<i4"), buf[20 * n:24 * n].view("<i4"))
 
     def _buffers(self):
         if self.fresh_outputs or self._bufs is None:

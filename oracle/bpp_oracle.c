@@ -467,21 +467,23 @@ int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear
 }
 
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
-                        const int32_t *counter, int32_t E, bpp_finished_row *rows_dev, bpp_finished_row *rows_host, int32_t n,
-                        void *stream) {
+                        const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
     (void)stream;
-    if (!done || !ep_ret || !ratio || !ep_len || !counter || !rows_dev || !rows_host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !dev || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
     if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    unsigned char *out = (unsigned char *)dev;
+    double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
+    int32_t *o_len = (int32_t *)(o_ratio + n), *o_cnt = o_len + n, *o_bin = o_cnt + n;
     int k = 0;
     for (int e = 0; e < E; ++e)
         if (done[e]) {
-            bpp_finished_row r = {ep_ret[e], ratio[e], ep_len[e], counter[e], e, 0};
-            rows_dev[++k] = r;
+            if (k < n) o_ret[k] = ep_ret[e], o_ratio[k] = ratio[e], o_len[k] = ep_len[e], o_cnt[k] = counter[e], o_bin[k] = e;
+            ++k;
         }
-    bpp_finished_row h = {0.0, 0.0, 0, 0, k, 0};
-    rows_dev[0] = h;
+    memset(out, 0, 32);
+    *(int32_t *)out = k;
+    memmove(host, dev, (size_t)BPP_FINISHED_BYTES(n));
     if (k != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
-    memmove(rows_host, rows_dev, (size_t)(n + 1) * sizeof(bpp_finished_row));
     return 0;
 }
 

@@ -186,6 +186,9 @@ static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t 
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u));
 }
+static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {   // v_alignbyte_b32
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8u * (sh & 3u)));
+}
 static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t sel) {
     // v_perm_b32: bytes 0-3 come from b, bytes 4-7 from a; selector values >= 8 are constants (only 0x0c = 0 used)
     const uint64_t src = ((uint64_t)a << 32) | b;

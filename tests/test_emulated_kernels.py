@@ -273,32 +273,38 @@ def test_emulated_wide_reduction_equals_the_one_workgroup_form_on_many_rows(emu,
 
 
 def test_emulated_gather_finished_compacts_in_bin_order(emu, oracle):
-    """bpp_gather_finished (ordered compaction by one workgroup + header count) on the emulator == the oracle's loop:
-    sizes that are not multiples of the 16-bins-per-thread / 16 384-bins-per-round shape, none / all / sparse finished."""
+    """bpp_gather_finished (ordered compaction by one workgroup, header count, five arrays of n entries) on the emulator ==
+    the oracle's loop: sizes that are not multiples of the 16-bins-per-thread / 16 384-bins-per-round shape, none / all /
+    sparse finished; a count that belongs to another step is refused."""
+    import ctypes
     rng = np.random.RandomState(11)
-    row = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("bin", "<i4"), ("reserved", "<i4")])
     for E, p in ((1, 1.0), (17, 0.5), (1000, 0.1), (16384, 0.11), (16385 + 77, 0.11), (40000, 0.0), (333, 1.0)):
         done = (rng.rand(E) < p).astype(np.uint8) * rng.randint(1, 3, size=E).astype(np.uint8)
         ret, ratio = rng.rand(E) * 10, rng.rand(E)
         ln, cnt = rng.randint(1, 60, size=E).astype(np.int32), rng.randint(0, 50, size=E).astype(np.int32)
         n = int(np.count_nonzero(done))
+        nb = (32 + 28 * E + 4 + 7) // 8 * 8
         got = {}
         for name, lib in (("oracle", oracle.lib()), ("emu", emu.lib())):
-            dev, host = np.zeros(E + 1, row), np.zeros(E + 1, row)
             lib.bpp_gather_finished.argtypes = None
-            import ctypes
-            rc = lib.bpp_gather_finished(ctypes.c_void_p(done.ctypes.data), ctypes.c_void_p(ret.ctypes.data), ctypes.c_void_p(ratio.ctypes.data),
-                                         ctypes.c_void_p(ln.ctypes.data), ctypes.c_void_p(cnt.ctypes.data), ctypes.c_int32(E),
-                                         ctypes.c_void_p(dev.ctypes.data), ctypes.c_void_p(host.ctypes.data), ctypes.c_int32(n), None)
+
+            def call(count):
+                dev, host = np.zeros(nb // 8, np.float64).view(np.uint8), np.full(nb // 8, -1.0).view(np.uint8)
+                rc = lib.bpp_gather_finished(ctypes.c_void_p(done.ctypes.data), ctypes.c_void_p(ret.ctypes.data),
+                                             ctypes.c_void_p(ratio.ctypes.data), ctypes.c_void_p(ln.ctypes.data),
+                                             ctypes.c_void_p(cnt.ctypes.data), ctypes.c_int32(E), ctypes.c_void_p(dev.ctypes.data),
+                                             ctypes.c_void_p(host.ctypes.data), ctypes.c_int32(count), None)
+                return rc, host
+            rc, host = call(n)
             assert rc == 0, lib.bpp_last_error()
-            assert host[0]["bin"] == n
-            got[name] = host[1:n + 1].copy()
-            # a count that belongs to another step is refused
-            assert lib.bpp_gather_finished(ctypes.c_void_p(done.ctypes.data), ctypes.c_void_p(ret.ctypes.data), ctypes.c_void_p(ratio.ctypes.data),
-                                           ctypes.c_void_p(ln.ctypes.data), ctypes.c_void_p(cnt.ctypes.data), ctypes.c_int32(E),
-                                           ctypes.c_void_p(dev.ctypes.data), ctypes.c_void_p(host.ctypes.data), ctypes.c_int32(n + 1 if n < E else n - 1), None) != 0
+            assert host[:4].view("<i4")[0] == n
+            b = host[32:32 + 28 * n]
+            got[name] = dict(ret=b[:8 * n].view("<f8").copy(), ratio=b[8 * n:16 * n].view("<f8").copy(), ln=b[16 * n:20 * n].view("<i4").copy(),
+                             cnt=b[20 * n:24 * n].view("<i4").copy(), bins=b[24 * n:28 * n].view("<i4").copy())
+            assert call(n + 1 if n < E else n - 1)[0] != 0          # the caller's `done` is not this step's
         idx = np.flatnonzero(done)
-        np.testing.assert_array_equal(got["oracle"]["bin"], idx)
-        np.testing.assert_array_equal(got["oracle"]["ep_ret"], ret[idx])
-        for f in row.names:
+        np.testing.assert_array_equal(got["oracle"]["bins"], idx)
+        np.testing.assert_array_equal(got["oracle"]["ret"], ret[idx])
+        np.testing.assert_array_equal(got["oracle"]["cnt"], cnt[idx])
+        for f in got["oracle"]:
             np.testing.assert_array_equal(got["emu"][f], got["oracle"][f], err_msg=f)
