@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--stream", action="store_true",
                     help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
                          "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
+    ap.add_argument("--stream-rng", choices=("mt19937", "counter"), default="mt19937",
+                    help="--stream: mt19937 = every bin an exact random.Random(seed + id) (sequences identical to the reference "
+                         "creator's under that seed); counter = the same cutting algorithm on a stateless counter-based generator "
+                         "(distribution parity, SURVEY 8f2's bar)")
     ap.add_argument("--stream-depth", type=int, default=32, help="--stream: ring rows per bin")
     ap.add_argument("--stream-refill", type=int, default=14,
                     help="--stream: lock-steps between refills (with depth >= 2 * refill + 3 the refills run beside the lock-steps)")
@@ -309,7 +313,7 @@ def main():
 
     env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=None if args.stream else pool, device=device,
                             env_id_base=rank * E, env_id_total=world * E,
-                            stream=dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill) if args.stream else None)
+                            stream=dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill, rng=args.stream_rng) if args.stream else None)
     stats = bpp_amd.EpisodeStats(device)
     actions = torch.empty(E, dtype=torch.int64, device=device)
     env.reset()
@@ -471,7 +475,9 @@ def main():
     if rank == 0:
         headline = size == (10, 10, 10) and not args.rotation and E == 65536 and not args.stream
         metric = "env steps/sec (whole node), %dx%dx%d bin%s, %d envs per GPU%s; bit-exact mask vs ref" % (
-            size + (" + rotation" if args.rotation else "", E, ", endless device-generated CUT-2 supply" if args.stream else ""))
+            size + (" + rotation" if args.rotation else "", E,
+                    ", endless device-generated CUT-2 supply (%s)" % ("exact CPython MT19937 streams" if args.stream_rng == "mt19937" else
+                                                                       "counter-based generator") if args.stream else ""))
         if headline:    # BASELINE.json's metric string belongs to its own workload only
             try:
                 metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -502,8 +508,10 @@ def main():
                                    % (size + (" + rotation" if args.rotation else "", E,
                                               " [--past-l3-only: EVERY region writes rotating output sets]" if only_sets else "")),
                        "envs_per_gpu": E, "total_envs": world * E, "pool_sequences": int(pool.shape[0]),
-                       "pool_source": ("device stream: random.Random(g) per bin, ring of %d rows, refill every %d lock-steps%s (bpp_stream)"
-                                       % (args.stream_depth, args.stream_refill,
+                       "pool_source": ("device stream: %s, ring of %d rows, refill every %d lock-steps%s (bpp_stream)"
+                                       % ("random.Random(g) per bin" if args.stream_rng == "mt19937" else
+                                          "counter-based generator keyed by (seed, bin, episode), the reference's cutting algorithm",
+                                          args.stream_depth, args.stream_refill,
                                           " beside the lock-steps" if args.stream_depth >= 2 * args.stream_refill + 3
                                           and bpp_amd._lib.get_knobs()["stream_overlap"] else "") if args.stream
                                        else args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)"),

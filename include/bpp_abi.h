@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 11
+#define BPP_ABI_VERSION 12
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -115,7 +115,28 @@ typedef struct bpp_batch {
  * four-kernel pipeline scan / pretwist / cut / sort of csrc/bpp_stream_gen.inl, else one lane per bin).
  * `mt` and `work` are opaque; bpp_stream_sizes tells how large they must be (both 16-byte aligned).  `mt` is an
  * array of num_envs equal records, one per bin (copy a bin's record together with its ring rows and gen_next to
- * clone its item stream; checkpoint the whole buffer); `work` is scratch between calls. */
+ * clone its item stream; checkpoint the whole buffer); `work` is scratch between calls.
+ *
+ * rng = BPP_STREAM_RNG_COUNTER: the same cutting algorithm (mdCreator.py:59-138, statement for statement) drawing from
+ * a COUNTER-BASED generator instead of CPython's Mersenne Twister -- the survey's bar for this row is distribution
+ * parity ("RNG streams can't match Python's random"); the exact stream above exceeds it and pays for it: a 6.6 KB state
+ * per bin, a kernel that regenerates states, rejection loops over a serial output stream.  Here a sequence is a pure
+ * function of (seed0, the bin's stream id, the episode index): no state, no regeneration, every draw independent of the
+ * one before.  Normative definition (the oracle library, the device kernels and sequences.CounterRandom follow it):
+ *     fmix32(x):  x ^= x >> 16;  x *= 0x85ebca6b;  x ^= x >> 13;  x *= 0xc2b2ae35;  x ^= x >> 16        (uint32)
+ *     key of episode k of stream id sid (uint64, initially the bin's global id):
+ *         h = fmix32((uint32)seed0 + 0x9E3779B9);  h = fmix32(h ^ (uint32)(seed0 >> 32));
+ *         h = fmix32(h ^ (uint32)sid);             h = fmix32(h ^ (uint32)(sid >> 32));
+ *         klo = fmix32(h ^ k);                     khi = fmix32(klo + 0x7F4A7C15 + k)
+ *     word(n, a) = fmix32((klo + n * 0x9E3779B9) ^ (khi + a * 0x85EBCA77))            n = index of the draw, a = attempt
+ *     below(lim), the n-th draw of the sequence (random.choice(flags) = flags[below(len)], random.randint(1, v) = 1 +
+ *     below(v)):  a = 0;  m = (uint64)word(n, a) * lim;  if (uint32)m < lim:  t = (2^32 - lim) mod lim;  while (uint32)m <
+ *     t:  a += 1, m = (uint64)word(n, a) * lim;   result = m >> 32          (Lemire's unbiased multiply-shift)
+ * A bin's record is then 16 bytes: its stream id (copied with the record when a bin is cloned, so that the copy
+ * continues the SOURCE's stream).  Uniformity of every draw is what makes the distribution of sequences the
+ * reference's; tests/test_stream_counter.py compares item-size and sequence-length statistics of the two generators. */
+#define BPP_STREAM_RNG_MT19937 0
+#define BPP_STREAM_RNG_COUNTER 1
 typedef struct bpp_stream {
     int32_t num_envs;      /* E                                                                    */
     int32_t depth;         /* D >= 4: ring rows per bin                                           */
@@ -130,6 +151,8 @@ typedef struct bpp_stream {
     int32_t *gen_next;     /* [E] next episode index to be generated                               */
     const bpp_env_state *state; /* [E] == bpp_batch.state (read: episode)                          */
     int32_t *overflow;     /* NULL or [1]: incremented per truncated sequence                      */
+    int32_t rng;           /* BPP_STREAM_RNG_MT19937 (exact CPython stream) / BPP_STREAM_RNG_COUNTER            */
+    int32_t reserved1;
 } bpp_stream;
 
 /* out[0] = uint32 words of `mt`, out[1] = bytes of `work` for the geometry in *s (num_envs, depth, pool_len, W, L, H

@@ -59,6 +59,43 @@ static uint32_t bpp_mt_below(bpp_mt *r, uint32_t n) {
     return x;
 }
 
+/* ---- counter-based generator of BPP_STREAM_RNG_COUNTER (normative definition: include/bpp_abi.h) ---- */
+typedef struct { uint32_t klo, khi, n; } bpp_ctr;
+
+static uint32_t bpp_fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+static bpp_ctr bpp_ctr_key(uint64_t seed0, uint64_t sid, uint32_t k) {
+    uint32_t h = bpp_fmix32((uint32_t)seed0 + 0x9E3779B9u);
+    h = bpp_fmix32(h ^ (uint32_t)(seed0 >> 32));
+    h = bpp_fmix32(h ^ (uint32_t)sid);
+    h = bpp_fmix32(h ^ (uint32_t)(sid >> 32));
+    bpp_ctr c;
+    c.klo = bpp_fmix32(h ^ k);
+    c.khi = bpp_fmix32(c.klo + 0x7F4A7C15u + k);
+    c.n = 0;
+    return c;
+}
+static uint32_t bpp_ctr_word(const bpp_ctr *c, uint32_t a) {
+    return bpp_fmix32((c->klo + c->n * 0x9E3779B9u) ^ (c->khi + a * 0x85EBCA77u));
+}
+static uint32_t bpp_ctr_below(bpp_ctr *c, uint32_t lim) {   /* Lemire's unbiased multiply-shift; one draw index per call */
+    uint32_t a = 0;
+    uint64_t m = (uint64_t)bpp_ctr_word(c, a) * lim;
+    if ((uint32_t)m < lim) {
+        const uint32_t t = (0u - lim) % lim;
+        while ((uint32_t)m < t) m = (uint64_t)bpp_ctr_word(c, ++a) * lim;
+    }
+    c->n += 1;
+    return (uint32_t)(m >> 32);
+}
+
+/* the two generators behind one call: `below(rng, n)` */
+typedef uint32_t (*bpp_below_fn)(void *, uint32_t);
+static uint32_t bpp_below_mt(void *r, uint32_t n) { return bpp_mt_below((bpp_mt *)r, n); }
+static uint32_t bpp_below_ctr(void *r, uint32_t n) { return bpp_ctr_below((bpp_ctr *)r, n); }
+
 /* ---- envs/bpp0/mdCreator.py:59-166 ---------------------------------------------------------------- */
 typedef struct { int x, y, z, low, high; } bpp_cut;
 
@@ -68,13 +105,12 @@ static int bpp_cmp_low(const void *a, const void *b) {  /* stable sort by low_bo
     return p->high < q->high ? -1 : (p->high > q->high ? 1 : 0);  /* `high` temporarily holds the original index */
 }
 
-/* one sequence from a running random.Random stream; returns the number of items, writes at most cap of them */
-static int bpp_cut2_from_stream(bpp_mt *rngp, int W, int L, int H, int lo, int hi, uint8_t *out, int cap) {
+/* one sequence drawn through `below`; returns the number of items, writes at most cap of them */
+static int bpp_cut2_walk(bpp_below_fn below, void *rngp, int W, int L, int H, int lo, int hi, uint8_t *out, int cap) {
     int vol = W * L * H, maxn = vol / (lo * lo * lo) + 8;
     bpp_cut *valid = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn);
     bpp_cut *inv = (bpp_cut *)malloc(sizeof(bpp_cut) * (size_t)maxn * 2);
     int nv = 0, ni = 0;
-#define rng (*rngp)
     inv[ni++] = (bpp_cut){W, L, H, 0, H};
     while (ni) {
         int i = 0;
@@ -84,23 +120,23 @@ static int bpp_cut2_from_stream(bpp_mt *rngp, int W, int L, int H, int lo, int h
             if (b.x > hi) flags[nf++] = 0;
             if (b.y > hi) flags[nf++] = 1;
             if (b.z > hi) flags[nf++] = 2;
-            int f = flags[bpp_mt_below(&rng, (uint32_t)nf)];   /* random.choice, :68 */
+            int f = flags[below(rngp, (uint32_t)nf)];   /* random.choice, :68 */
             bpp_cut s1, s2;
             if (f == 0) {                       /* :70-79 */
                 if (b.x <= lo) continue;
-                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.x);   /* random.randint(1, x) */
+                int r = 1 + (int)below(rngp, (uint32_t)b.x);   /* random.randint(1, x) */
                 if (r < lo || b.x - r < lo) continue;
                 s1 = (bpp_cut){r, b.y, b.z, b.low, b.high};
                 s2 = (bpp_cut){b.x - r, b.y, b.z, b.low, b.high};
             } else if (f == 1) {                /* :80-89 */
                 if (b.y < lo) continue;
-                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.y);
+                int r = 1 + (int)below(rngp, (uint32_t)b.y);
                 if (r < lo || b.y - r < lo) continue;
                 s1 = (bpp_cut){b.x, r, b.z, b.low, b.high};
                 s2 = (bpp_cut){b.x, b.y - r, b.z, b.low, b.high};
             } else {                            /* :90-99 */
                 if (b.z < lo) continue;
-                int r = 1 + (int)bpp_mt_below(&rng, (uint32_t)b.z);
+                int r = 1 + (int)below(rngp, (uint32_t)b.z);
                 if (r < lo || b.z - r < lo) continue;
                 s1 = (bpp_cut){b.x, b.y, b.z - r, b.low, b.high - r};
                 s2 = (bpp_cut){b.x, b.y, r, b.high - r, b.high};
@@ -125,8 +161,17 @@ static int bpp_cut2_from_stream(bpp_mt *rngp, int W, int L, int H, int lo, int h
     }
     free(valid);
     free(inv);
-#undef rng
     return nv;
+}
+
+/* one sequence from a running random.Random stream */
+static int bpp_cut2_from_stream(bpp_mt *rngp, int W, int L, int H, int lo, int hi, uint8_t *out, int cap) {
+    return bpp_cut2_walk(bpp_below_mt, rngp, W, L, H, lo, hi, out, cap);
+}
+/* episode k of counter stream (seed0, sid) */
+static int bpp_cut2_counter(uint64_t seed0, uint64_t sid, uint32_t k, int W, int L, int H, int lo, int hi, uint8_t *out, int cap) {
+    bpp_ctr c = bpp_ctr_key(seed0, sid, k);
+    return bpp_cut2_walk(bpp_below_ctr, &c, W, L, H, lo, hi, out, cap);
 }
 
 /* sequence of a fresh random.Random(seed) */

@@ -17,7 +17,8 @@ LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 11   # (bpp_gather_finished, the acc_reduce scratch and the byte-sized stream records all arrived in 11)
+ABI_VERSION = 12
+STREAM_RNG_MT19937, STREAM_RNG_COUNTER = 0, 1
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
 REDUCE_LANES = 1024
@@ -43,7 +44,8 @@ class Stream(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("depth", ctypes.c_int32), ("pool_len", ctypes.c_int32), ("W", ctypes.c_int32),
                 ("L", ctypes.c_int32), ("H", ctypes.c_int32), ("bound_lo", ctypes.c_int32), ("bound_hi", ctypes.c_int32),
                 ("env_id_base", ctypes.c_int64), ("seed0", ctypes.c_uint64), ("ring", ctypes.c_void_p), ("mt", ctypes.c_void_p),
-                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p)]
+                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p),
+                ("rng", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
 POOL_STATIC, POOL_RING = 0, 1

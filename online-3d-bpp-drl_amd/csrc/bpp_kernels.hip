@@ -2569,6 +2569,7 @@ int check_stream(const bpp_stream *s) {
         return fail(BPP_E_BADARG, "bpp_stream: bin / bounds the reference generator cannot cut");
     if (((uintptr_t)s->ring & 3u) || ((uintptr_t)s->work & 15u) || ((uintptr_t)s->mt & 15u))
         return fail(BPP_E_BADARG, "bpp_stream: misaligned buffer");
+    if (s->rng != BPP_STREAM_RNG_MT19937 && s->rng != BPP_STREAM_RNG_COUNTER) return fail(BPP_E_BADARG, "bpp_stream: unknown rng");
     return 0;
 }
 
@@ -2607,8 +2608,9 @@ int bpp_stream_sizes(const bpp_stream *s, int64_t out[2]) {
     if (!s || !out) return fail(BPP_E_BADARG, "bpp_stream_sizes: NULL pointer");
     if (s->num_envs <= 0 || s->depth < 4 || !bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi))
         return fail(BPP_E_BADARG, "bpp_stream_sizes: fill in num_envs, depth, pool_len, the bin and the bounds first");
+    if (s->rng != BPP_STREAM_RNG_MT19937 && s->rng != BPP_STREAM_RNG_COUNTER) return fail(BPP_E_BADARG, "bpp_stream_sizes: unknown rng");
     const StreamPlan p = plan_stream(s);
-    out[0] = (int64_t)kMtRec * s->num_envs;
+    out[0] = (int64_t)(s->rng == BPP_STREAM_RNG_COUNTER ? kCtrRec : kMtRec) * s->num_envs;
     out[1] = (int64_t)(p.fast_bytes > p.legacy_bytes ? p.fast_bytes : p.legacy_bytes);
     return 0;
 }
@@ -2644,10 +2646,16 @@ int stream_refill(const bpp_stream *s, void *stream, int kmax, int urgent) {
     const int E = s->num_envs;
     hipLaunchKernelGGL(stream_scan_kernel, dim3((E + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 2 * (kScanThreads / 64) * 4 * sizeof(int), st,
                        *s, w);
-    hipLaunchKernelGGL(stream_pretwist_kernel, dim3((unsigned)((E + 3) / 4 < 2048 ? (E + 3) / 4 : 2048)), dim3(256),
-                       4 * kTwistWords * sizeof(uint32_t), st, *s, w);
-    if (p.fb == 4) hipLaunchKernelGGL(stream_cut_kernel<4>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
-    else hipLaunchKernelGGL(stream_cut_kernel<8>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+    if (s->rng == BPP_STREAM_RNG_COUNTER) {      // no generator state: nothing to regenerate, the lists are all the LDS a cut wave needs
+        const size_t lds = (size_t)stream_cut_lds_bytes(p.cap, p.fb) - (size_t)64 * kRingStride;
+        if (p.fb == 4) hipLaunchKernelGGL(stream_cut_ctr_kernel<4>, dim3(p.nslots / 64), dim3(64), lds, st, *s, w);
+        else hipLaunchKernelGGL(stream_cut_ctr_kernel<8>, dim3(p.nslots / 64), dim3(64), lds, st, *s, w);
+    } else {
+        hipLaunchKernelGGL(stream_pretwist_kernel, dim3((unsigned)((E + 3) / 4 < 2048 ? (E + 3) / 4 : 2048)), dim3(256),
+                           4 * kTwistWords * sizeof(uint32_t), st, *s, w);
+        if (p.fb == 4) hipLaunchKernelGGL(stream_cut_kernel<4>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+        else hipLaunchKernelGGL(stream_cut_kernel<8>, dim3(p.nslots / 64), dim3(64), p.cut_lds, st, *s, w);
+    }
     const int64_t most = ((int64_t)E * s->depth + 3) / 4;
     hipLaunchKernelGGL(stream_sort_kernel, dim3((unsigned)(most < 2048 ? most : 2048)), dim3(256), p.sort_lds, st, *s, w);
     e = hipGetLastError();

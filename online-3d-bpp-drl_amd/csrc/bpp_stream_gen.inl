@@ -20,13 +20,48 @@ struct CutBox {
 constexpr uint32_t kAlive = 0x80000000u;
 
 template <class Rng>
-__host__ __device__ inline uint32_t rand_below(Rng &rng, uint32_t n) {   // Random._randbelow_with_getrandbits(n), 0 < n < 2^32
+__host__ __device__ inline uint32_t getrandbits_below(Rng &rng, uint32_t n) {   // Random._randbelow_with_getrandbits(n), 0 < n < 2^32
     int k = 0;
     for (uint32_t v = n; v; v >>= 1) ++k;
     uint32_t x = rng.u32() >> (32 - k);
     while (x >= n) x = rng.u32() >> (32 - k);
     return x;
 }
+
+// ---- the counter-based generator of BPP_STREAM_RNG_COUNTER (normative definition: include/bpp_abi.h) -----------------
+__host__ __device__ inline uint32_t ctr_fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85ebca6bu;
+    x ^= x >> 13;
+    x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+struct CtrRng {
+    uint32_t klo, khi, n;
+    __host__ __device__ static CtrRng key(uint64_t seed0, uint64_t sid, uint32_t k) {
+        uint32_t h = ctr_fmix32((uint32_t)seed0 + 0x9E3779B9u);
+        h = ctr_fmix32(h ^ (uint32_t)(seed0 >> 32));
+        h = ctr_fmix32(h ^ (uint32_t)sid);
+        h = ctr_fmix32(h ^ (uint32_t)(sid >> 32));
+        CtrRng c;
+        c.klo = ctr_fmix32(h ^ k);
+        c.khi = ctr_fmix32(c.klo + 0x7F4A7C15u + k);
+        c.n = 0;
+        return c;
+    }
+    __host__ __device__ uint32_t word(uint32_t a) const { return ctr_fmix32((klo + n * 0x9E3779B9u) ^ (khi + a * 0x85EBCA77u)); }
+    __host__ __device__ uint32_t below(uint32_t lim) {      // Lemire's unbiased multiply-shift; one draw index per call
+        uint32_t a = 0;
+        uint64_t m = (uint64_t)word(a) * lim;
+        if ((uint32_t)m < lim) {                            // probability lim / 2^32
+            const uint32_t t = (0u - lim) % lim;
+            while ((uint32_t)m < t) m = (uint64_t)word(++a) * lim;
+        }
+        n += 1;
+        return (uint32_t)(m >> 32);
+    }
+};
 
 // One CUT-2 sequence, every box side in [lo, hi].  `work` is the pending list (get / set by index, capacity >=
 // W*L*H / lo^3 + 8), `vals` collects the cut boxes as x | y<<8 | z<<16 | base height<<24 and sorts them.  Returns the
@@ -56,23 +91,23 @@ __host__ __device__ inline int cut2_generate(Rng &rng, Work &work, Vals &vals, i
             if (bx > hi) flags[nf++] = 0;
             if (by > hi) flags[nf++] = 1;
             if (bz > hi) flags[nf++] = 2;
-            const int f = flags[rand_below(rng, (uint32_t)nf)];   // random.choice, :68
+            const int f = flags[rng.below((uint32_t)nf)];           // random.choice, :68
             int s1[5], s2[5];                   // x, y, z, low, high of the two parts
             if (f == 0) {                       // :70-79
                 if (bx <= lo) continue;
-                const int r = 1 + (int)rand_below(rng, (uint32_t)bx);   // random.randint(1, x)
+                const int r = 1 + (int)rng.below((uint32_t)bx);         // random.randint(1, x)
                 if (r < lo || bx - r < lo) continue;
                 s1[0] = r, s1[1] = by, s1[2] = bz, s1[3] = low, s1[4] = high;
                 s2[0] = bx - r, s2[1] = by, s2[2] = bz, s2[3] = low, s2[4] = high;
             } else if (f == 1) {                // :80-89
                 if (by < lo) continue;
-                const int r = 1 + (int)rand_below(rng, (uint32_t)by);
+                const int r = 1 + (int)rng.below((uint32_t)by);
                 if (r < lo || by - r < lo) continue;
                 s1[0] = bx, s1[1] = r, s1[2] = bz, s1[3] = low, s1[4] = high;
                 s2[0] = bx, s2[1] = by - r, s2[2] = bz, s2[3] = low, s2[4] = high;
             } else {                            // :90-99
                 if (bz < lo) continue;
-                const int r = 1 + (int)rand_below(rng, (uint32_t)bz);
+                const int r = 1 + (int)rng.below((uint32_t)bz);
                 if (r < lo || bz - r < lo) continue;
                 s1[0] = bx, s1[1] = by, s1[2] = bz - r, s1[3] = low, s1[4] = high - r;
                 s2[0] = bx, s2[1] = by, s2[2] = r, s2[3] = high - r, s2[4] = high;
@@ -167,6 +202,7 @@ struct StridedMT {
         y ^= y >> 18;
         return y;
     }
+    __host__ __device__ uint32_t below(uint32_t n) { return getrandbits_below(*this, n); }
 };
 
 // host-side storages (bpp_gen_cut2): plain arrays
@@ -201,6 +237,7 @@ constexpr int kMtOut8Bytes = 2 * kMtHalf + kMtMirrorLen;       // 1504
 constexpr int kMtRec = kMtOut8 + kMtOut8Bytes / 4;           // 1656 words = 6 624 bytes
 static_assert(kMtOut8Bytes % 4 == 0 && (kMtRec * 4) % 16 == 0, "records stay 16-byte aligned");
 __host__ __device__ inline uint8_t *mt_out8(uint32_t *rec) { return (uint8_t *)(rec + kMtOut8); }
+constexpr int kCtrRec = 4;      // BPP_STREAM_RNG_COUNTER: words per bin -- the 64-bit stream id (+ 2 reserved)
 
 __host__ __device__ inline int stream_work_entries(int W, int L, int H, int lo) { return W * L * H / (lo * lo * lo) + 8; }
 
@@ -765,6 +802,179 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
 // most) never touch LDS: a lane holds one box, its place is the number of boxes with a lower base plus the number of
 // equal ones in lower lanes, counted with one ballot per distinct base height; the next row's boxes are loaded before
 // the current row is ranked.  Longer rows are staged in LDS and ranked chunk by chunk.
+// ======================================================================================================================
+// BPP_STREAM_RNG_COUNTER, fast pipeline: scan / cut / sort (no pretwist: there is no state to regenerate).  The cut kernel
+// is the list walk of stream_cut_kernel without everything the Mersenne Twister forced on it: a draw is a hash of (key,
+// draw index) -- no ring of outputs, no top-ups, no fetches --, a rejection happens once in 2^32 / lim draws -- no
+// eight-candidate min-trees, a visit is always decided in the iteration that starts it.  Same lists (ListCol / PendLists),
+// same unsorted row format, same sort kernel.
+// ======================================================================================================================
+struct CtrLane {
+    uint32_t box;
+    int i, tail_a, tail_b;  // position in this pass's list, its length, length of the survivors' list
+    int side;               // which LDS list is this pass's (0 / 1)
+    int nv;                 // boxes cut so far
+    uint32_t *row;
+    CtrRng rng;
+};
+
+// One visit for a lane whose lists are certain to stay inside LDS: mdCreator.py:59-100 + :120-130 without divergent
+// branches (the one that exists -- a rejected draw -- is taken by nobody in 2^32 / lim - 1 of 2^32 / lim cases).
+template <int FB>
+__device__ __forceinline__ uint32_t cut_visit_ctr(CtrLane &c, const ListCol<FB> col, int cap, uint32_t act, uint32_t lo, uint32_t hi) {
+    constexpr uint32_t FM = (1u << FB) - 1u;
+    const uint32_t dummy = 2u * (uint32_t)cap;
+    const uint32_t abase = (uint32_t)cap & (0u - (uint32_t)c.side), bbase = (uint32_t)cap - abase;
+    const uint32_t box = c.box;
+    const uint32_t bx = box & FM, by = (box >> FB) & FM, bz = (box >> (2 * FB)) & FM;
+    const uint32_t mfx = m_lt(hi, bx), mfy = m_lt(hi, by), mfz = m_lt(hi, bz);          // :60-66
+    const uint32_t nf = max(0u - (mfx + mfy + mfz), 1u);                                // (1 for a lane without a box: no draw from 0)
+    const uint32_t monly = m_eq(nf, 1u);
+    const uint32_t x1 = c.rng.below(nf);                                                // random.choice(flags), :68
+    const uint32_t f0 = (2u + mfy) & ~mfx;                                              // first long side
+    const uint32_t f1 = 2u + (mfx & mfy);                                               // second long side
+    const uint32_t f = m_sel(m_lt(x1, 1u), f0, m_sel(m_eq(x1, 1u), f1, 2u));
+    const uint32_t v = max((box >> ((uint32_t)FB * f)) & FM, 1u);
+    const uint32_t r = c.rng.below(v) + 1u;                                             // random.randint(1, v), :73 / :83 / :93
+    const uint32_t mgood = ~(m_lt(r, lo) | m_lt(v - r, lo));                            // :74, :84, :94
+    const uint32_t msplit = act & mgood, mfail = act & ~mgood;
+    const uint32_t mf2 = m_eq(f, 2u);
+    const uint32_t sh = (uint32_t)FB * f, p1 = m_sel(mf2, v - r, r), p2 = v - p1;
+    const uint32_t rest = box & ~(FM << sh);
+    const uint32_t c1 = rest | (p1 << sh);
+    const uint32_t c2 = (rest | (p2 << sh)) + ((p1 << (3 * FB)) & mf2);                 // :97-98: the upper part starts at high - r
+    const uint32_t me1 = msplit & monly & ~m_lt(hi, p1), me2 = msplit & monly & ~m_lt(hi, p2);   // is_valid, :110-115
+    const uint32_t mq1 = msplit & ~me1, mq2 = msplit & ~me2;
+    uint32_t nv = (uint32_t)c.nv, tail_a = (uint32_t)c.tail_a, tail_b = (uint32_t)c.tail_b, i = (uint32_t)c.i;
+    if (me1) c.row[nv] = c1;
+    nv -= me1;
+    if (me2) c.row[nv] = c2;
+    nv -= me2;
+    col.set(m_sel(mfail, bbase + tail_b, dummy), box);            // stays in invalid_box for the next pass
+    tail_b -= mfail;
+    col.set(m_sel(mq1, abase + tail_a, dummy), c1);               // appended: visited later in this pass
+    tail_a -= mq1;
+    col.set(m_sel(mq2, abase + tail_a, dummy), c2);
+    tail_a -= mq2;
+    i -= act;
+    // the two entries after the visited box (the first is skipped after a split, :124) and the head of the survivors
+    const uint32_t n1 = col.get(abase + min(i, (uint32_t)cap - 1u)), n2 = col.get(abase + min(i + 1u, (uint32_t)cap - 1u));
+    const uint32_t mskip = msplit & m_lt(i, tail_a);
+    col.set(m_sel(mskip, bbase + tail_b, dummy), n1);
+    tail_b -= mskip;
+    i -= mskip;
+    const uint32_t b0 = col.get(bbase);
+    const uint32_t mpass = act & ~m_lt(i, tail_a);                // end of the `for`: next pass over the survivors, or done
+    const uint32_t mdone = mpass & m_eq(tail_b, 0u);
+    c.box = m_sel(act, m_sel(mpass, b0, m_sel(mskip, n2, n1)), box);
+    c.side ^= (int)(mpass & 1u);
+    c.tail_a = (int)m_sel(mpass, tail_b, tail_a);
+    c.tail_b = (int)(tail_b & ~mpass);
+    c.i = (int)(i & ~mpass);
+    c.nv = (int)nv;
+    return mdone;
+}
+
+// The same visit in plain form for lists of any length (entries beyond the LDS part live in global memory): the
+// statement cut_visit_ctr is checked against; a wave runs it whenever one of its lanes' lists may leave LDS.
+template <int FB>
+__device__ __forceinline__ bool cut_visit_ctr_general(CtrLane &c, const PendLists<FB> &pend, uint32_t lo, uint32_t hi) {
+    constexpr uint32_t FM = (1u << FB) - 1u;
+    const uint32_t bx = c.box & FM, by = (c.box >> FB) & FM, bz = (c.box >> (2 * FB)) & FM;
+    const bool fx = bx > hi, fy = by > hi, fz = bz > hi;                    // :60-66
+    const uint32_t nf = (uint32_t)fx + (uint32_t)fy + (uint32_t)fz;
+    const uint32_t x1 = c.rng.below(nf);                                    // random.choice(flags), :68
+    const int f = x1 == 0u ? (fx ? 0 : (fy ? 1 : 2)) : (x1 == 1u ? ((fx && fy) ? 1 : 2) : 2);
+    const uint32_t v = f == 0 ? bx : (f == 1 ? by : bz);
+    const uint32_t r = c.rng.below(v) + 1u;                                 // random.randint(1, v)
+    const bool split = r >= lo && v - r >= lo;                              // :74, :84, :94
+    if (!split) {
+        pend.set(c.side ^ 1, c.tail_b++, c.box);                            // stays in invalid_box for the next pass
+    } else {
+        const uint32_t sh = (uint32_t)FB * (uint32_t)f, p1 = f == 2 ? v - r : r, p2 = v - p1;
+        const uint32_t rest = c.box & ~(FM << sh);
+        const uint32_t c1 = rest | (p1 << sh);
+        const uint32_t c2 = (rest | (p2 << sh)) + (f == 2 ? p1 << (3 * FB) : 0u);   // :97-98
+        if (nf == 1u && p1 <= hi) c.row[c.nv++] = c1;                       // is_valid (:110-115)
+        else pend.set(c.side, c.tail_a++, c1);
+        if (nf == 1u && p2 <= hi) c.row[c.nv++] = c2;
+        else pend.set(c.side, c.tail_a++, c2);
+    }
+    ++c.i;
+    if (split && c.i < c.tail_a) {                // the removal slid the next box under the iterator: not visited in this pass
+        pend.set(c.side ^ 1, c.tail_b++, pend.get(c.side, c.i));
+        ++c.i;
+    }
+    if (c.i < c.tail_a) {
+        c.box = pend.get(c.side, c.i);
+        return false;
+    }
+    const bool finished = c.tail_b == 0;          // end of the `for`: next pass over the survivors, or done
+    c.side ^= 1;
+    c.tail_a = c.tail_b;
+    c.tail_b = 0;
+    c.i = 0;
+    if (!finished) c.box = pend.get(c.side, 0);
+    return finished;
+}
+
+template <int FB>
+__global__ __launch_bounds__(64) void stream_cut_ctr_kernel(bpp_stream s, StreamWork w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int E = s.num_envs, T = s.pool_len, D = s.depth, cap = w.cap;
+    const uint32_t lo = (uint32_t)s.bound_lo, hi = (uint32_t)s.bound_hi;
+    // wave -> (bucket, position): the longest jobs are dispatched first
+    const int n3 = w.hdr[2], n2 = w.hdr[1], n1 = w.hdr[0];
+    const int w3 = (n3 + 63) >> 6, w2 = (n2 + 63) >> 6, w1 = (n1 + 63) >> 6;
+    int b = blockIdx.x, n, bucket;
+    if (b < w3) n = n3, bucket = 2;
+    else if (b < w3 + w2) b -= w3, n = n2, bucket = 1;
+    else if (b < w3 + w2 + w1) b -= w3 + w2, n = n1, bucket = 0;
+    else return;
+    const int j = b * 64 + lane;
+    const bool job = j < n;
+    const int e = job ? w.jobs[(size_t)bucket * E + j] : 0;
+    const ListCol<FB> col{(typename ListCol<FB>::T *)smem + lane};
+    const PendLists<FB> pend{col, w.spill + (size_t)blockIdx.x * 64 + lane, cap, w.nsp, (size_t)w.nslots};
+    int g = 0, need = 0;
+    uint64_t sid = 0;
+    if (job) {
+        const uint32_t *rc = s.mt + (size_t)e * kCtrRec;
+        sid = (uint64_t)rc[0] | ((uint64_t)rc[1] << 32);
+        g = s.gen_next[e];
+        need = w.target[e] - g;
+    }
+    bool active = job && need > 0;
+    const bool ran = active;
+    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << FB) | ((uint32_t)s.H << (2 * FB));
+    CtrLane c{whole, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T, CtrRng::key(s.seed0, sid, (uint32_t)g)};
+    if (active) col.set(0u, whole);
+    while (__ballot(active)) {
+        bool finished;
+        if (__ballot(active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap))) {   // wave-uniform: a list may leave LDS
+            finished = active ? cut_visit_ctr_general<FB>(c, pend, lo, hi) : false;
+        } else {
+            finished = cut_visit_ctr<FB>(c, col, cap, active ? ~0u : 0u, lo, hi) != 0u;
+        }
+        if (finished) {
+            c.row[T - 1] = (uint32_t)c.nv;            // length for the sort kernel (which restores the terminator)
+            ++g;
+            if (--need > 0) {
+                c.row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+                pend.set(c.side, 0, whole);
+                c.tail_a = 1;
+                c.nv = 0;
+                c.box = whole;
+                c.rng = CtrRng::key(s.seed0, sid, (uint32_t)g);
+            } else {
+                active = false;
+            }
+        }
+    }
+    if (ran) s.gen_next[e] = g;
+}
+
 // An unsorted box as the cut kernel leaves it (fields of w.fb bits) -> x | y << 8 | z << 16 | base height << 24.
 __device__ __forceinline__ uint32_t cut_box_bytes(uint32_t v, int fb) {
     return fb == 8 ? v : ((v & 15u) | ((v & 0xf0u) << 4) | ((v & 0xf00u) << 8) | ((v & 0xf000u) << 12));
@@ -962,12 +1172,20 @@ struct BufferedMT {
         }
         return buf[(pos++) * kStreamLanes];
     }
+    __device__ uint32_t below(uint32_t n) { return getrandbits_below(*this, n); }
 };
 
 // One lane per bin: seed the bin's generator with random.Random(seed0 + global id); nothing generated yet.
 __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= s.num_envs) return;
+    if (s.rng == BPP_STREAM_RNG_COUNTER) {   // the record is the bin's stream id
+        const uint64_t sid = (uint64_t)(s.env_id_base + e);
+        uint32_t *rec = s.mt + (size_t)e * kCtrRec;
+        rec[0] = (uint32_t)sid, rec[1] = (uint32_t)(sid >> 32), rec[2] = 0u, rec[3] = 0u;
+        s.gen_next[e] = 0;
+        return;
+    }
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
     StridedMT rng{rec + kMtRaw, 1, 624};     // into the first half; a freshly seeded state has no unused output (index 624)
     rng.seed(s.seed0 + (uint64_t)(s.env_id_base + e));
@@ -989,13 +1207,31 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
     const int cur = s.state[e].episode;
     int g = s.gen_next[e];
     if (g >= cur + D) return;
+    const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    LdsWork work{lds + lane, (CutBox *)s.work + e, (size_t)E};
+    int over = 0;
+    if (s.rng == BPP_STREAM_RNG_COUNTER) {   // every sequence a fresh generator keyed by (seed0, stream id, episode)
+        const uint32_t *rc = s.mt + (size_t)e * kCtrRec;
+        const uint64_t sid = (uint64_t)rc[0] | ((uint64_t)rc[1] << 32);
+        while (g < cur + D) {
+            uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+            LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1};
+            CtrRng rng = CtrRng::key(s.seed0, sid, (uint32_t)g);
+            const int n = cut2_generate(rng, work, vals, s.W, s.L, s.H, s.bound_lo, s.bound_hi);
+            over += n > T - 1;
+            const int nw = n < T - 1 ? n : T - 1;
+            for (int t = 0; t < nw; ++t) row[t] = vals.get(t) & 0x00ffffffu;
+            for (int t = nw; t < T; ++t) row[t] = term;
+            ++g;
+        }
+        s.gen_next[e] = g;
+        if (over && s.overflow) atomicAdd(s.overflow, over);
+        return;
+    }
     uint32_t *rec = s.mt + (size_t)e * kMtRec;
     const uint32_t par0 = rec[kMtPar];
     BufferedMT rng{rec, rec + kMtRaw + par0 * kMtHalf, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
                    (int)rec[kMtPos], 0, 0, par0, rec[kMtNextOk]};
-    LdsWork work{lds + lane, (CutBox *)s.work + e, (size_t)E};
-    const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
-    int over = 0;
     while (g < cur + D) {
         uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
         LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1};

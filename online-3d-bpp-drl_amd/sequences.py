@@ -67,6 +67,55 @@ def from_dataset(path, container_size=(10, 10, 10), terminator=(10, 10, 10), fir
     return check_pool(pad_pool(seqs, term), container_size)
 
 
+class CounterRandom(object):
+    """The counter-based generator of BPP_STREAM_RNG_COUNTER (normative definition: include/bpp_abi.h) with the two
+    methods the cutting algorithm calls on `random.Random`: episode `episode` of stream id `sid` under `seed0` is
+    cut2_sequence(size, bound, CounterRandom(seed0, sid, episode)).  Third statement of that generator, beside the oracle
+    library's C and the device kernels."""
+    M = 0xFFFFFFFF
+
+    @classmethod
+    def fmix32(cls, x):
+        x &= cls.M
+        x ^= x >> 16
+        x = (x * 0x85ebca6b) & cls.M
+        x ^= x >> 13
+        x = (x * 0xc2b2ae35) & cls.M
+        x ^= x >> 16
+        return x
+
+    def __init__(self, seed0, sid, episode):
+        f, M = self.fmix32, self.M
+        h = f((seed0 & M) + 0x9E3779B9)
+        h = f(h ^ ((seed0 >> 32) & M))
+        h = f(h ^ (sid & M))
+        h = f(h ^ ((sid >> 32) & M))
+        self.klo = f(h ^ (episode & M))
+        self.khi = f(self.klo + 0x7F4A7C15 + (episode & M))
+        self.n = 0
+
+    def _word(self, a):
+        M = self.M
+        return self.fmix32(((self.klo + self.n * 0x9E3779B9) & M) ^ ((self.khi + a * 0x85EBCA77) & M))
+
+    def below(self, lim):
+        a = 0
+        m = self._word(a) * lim
+        if (m & self.M) < lim:
+            t = ((1 << 32) - lim) % lim
+            while (m & self.M) < t:
+                a += 1
+                m = self._word(a) * lim
+        self.n += 1
+        return m >> 32
+
+    def choice(self, seq):
+        return seq[self.below(len(seq))]
+
+    def randint(self, a, b):
+        return a + self.below(b - a + 1)
+
+
 class _Cut(object):
     """A cuboid being cut (identity semantics, like the reference's Box objects)."""
     __slots__ = ("x", "y", "z", "low", "high")

@@ -246,10 +246,12 @@ class BppVecEnv(object):
     fresh_outputs:  allocate new output tensors every step (reference semantics: results of earlier
                     steps stay valid); False = reuse one set of buffers, results are valid until the
                     next step/reset call.
-    stream:         instead of `pool`: dict(bound=(lo, hi), seed=s, depth=D, refill_every=R) -- an endless CUT-2
-                    supply generated on the device (include/bpp_abi.h: bpp_stream).  Every bin owns an exact
+    stream:         instead of `pool`: dict(bound=(lo, hi), seed=s, depth=D, refill_every=R, rng="mt19937") -- an endless
+                    CUT-2 supply generated on the device (include/bpp_abi.h: bpp_stream).  Every bin owns an exact
                     random.Random(seed + global bin id); its k-th episode plays the k-th sequence that stream
-                    yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.  The ring
+                    yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.
+                    rng="counter": the same cutting algorithm on a counter-based generator (distribution parity,
+                    SURVEY 8f2's bar; no per-bin state, no regeneration kernel -- the fast supply).  The ring
                     is refilled every R <= D - 3 lock-steps (default D = 8, R = 5); `rollout_uniform` runs the
                     refills beside the lock-steps when D >= 2 R + 3 (e.g. D = 32, R = 14).  Costs 11 KB of
                     generator state per bin plus D rows of W*L*H / lo^3 + 1 entries.
@@ -304,7 +306,8 @@ class BppVecEnv(object):
                     raise ValueError("refill_every must be in 1 .. depth - 3")
                 self.pool = torch.zeros((depth * self.E, pool_len, 4), dtype=torch.uint8, device=dev)   # the ring
                 sizes = (ctypes.c_int64 * 2)()      # the two opaque buffers of a bpp_stream: generator records, scratch
-                probe = _lib.Stream(self.E, depth, pool_len, self.W, self.L, self.H, lo, hi, 0, 0, None, None, None, None, None, None)
+                rng = {"mt19937": _lib.STREAM_RNG_MT19937, "counter": _lib.STREAM_RNG_COUNTER}[stream.get("rng", "mt19937")]
+                probe = _lib.Stream(self.E, depth, pool_len, self.W, self.L, self.H, lo, hi, 0, 0, None, None, None, None, None, None, rng, 0)
                 _lib.check(self.lib.bpp_stream_sizes(ctypes.byref(probe), sizes))
                 self._mt = torch.zeros((self.E, int(sizes[0]) // self.E), dtype=torch.int32, device=dev)
                 self._work = torch.zeros(((int(sizes[1]) + 15) // 16, 4), dtype=torch.int32, device=dev)
@@ -312,7 +315,7 @@ class BppVecEnv(object):
                 self.stream_overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
                 pool_rows, pool_mode = depth * self.E, _lib.POOL_RING
                 self.stream_spec = dict(bound=(lo, hi), seed=int(stream.get("seed", 0)), depth=depth, pool_len=pool_len,
-                                        refill_every=self.refill_every)
+                                        refill_every=self.refill_every, rng=stream.get("rng", "mt19937"))
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
             self.state = torch.zeros((self.E, 12), dtype=torch.int32, device=dev)  # bpp_env_state[E], 48 B each
             # episode statistics kept inside the step kernel, one row per bin: [return sum, final-ratio sum, length
@@ -330,7 +333,8 @@ class BppVecEnv(object):
             self._stream = _lib.Stream(self.E, sp["depth"], sp["pool_len"], self.W, self.L, self.H, sp["bound"][0], sp["bound"][1],
                                        self.env_id_base, sp["seed"], self.pool.data_ptr(), self._mt.data_ptr(),
                                        self._work.data_ptr(), self.gen_next.data_ptr(), self.state.data_ptr(),
-                                       self.stream_overflow.data_ptr())
+                                       self.stream_overflow.data_ptr(),
+                                       {"mt19937": _lib.STREAM_RNG_MT19937, "counter": _lib.STREAM_RNG_COUNTER}[sp["rng"]], 0)
             with torch.cuda.device(dev):
                 _lib.check(self.lib.bpp_stream_init(ctypes.byref(self._stream), self._stream_ptr()))
             self.refill()
@@ -803,7 +807,7 @@ class BppVecEnv(object):
         """What must agree for a streaming checkpoint to continue the same item streams."""
         sp = self.stream_spec
         return dict(bound=tuple(sp["bound"]), seed=sp["seed"], depth=sp["depth"], pool_len=sp["pool_len"],
-                    num_envs=self.E, env_id_base=self.env_id_base, bin_size=self.bin_size)
+                    num_envs=self.E, env_id_base=self.env_id_base, bin_size=self.bin_size, rng=sp["rng"])
 
     def load_state_dict(self, sd):
         if self._stream is None and "stream_ring" in sd:
@@ -812,6 +816,9 @@ class BppVecEnv(object):
             if "stream_ring" not in sd:
                 raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
             want, got = self._stream_identity(), sd.get("stream_spec")
+            if got is not None:
+                got = dict(got)
+                got.setdefault("rng", "mt19937")      # checkpoints older than the counter generator
             if got is not None and dict(got) != want:
                 raise ValueError("checkpoint stream_spec %r does not match this env's %r" % (dict(got), want))
             if tuple(sd["stream_ring"].shape) != tuple(self.pool.shape) or tuple(sd["stream_mt"].shape) != tuple(self._mt.shape):

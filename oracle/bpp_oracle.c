@@ -693,13 +693,15 @@ static int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
     if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0) return fail(BPP_E_BADARG, "bpp_stream: bad size");
     if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi)) return fail(BPP_E_BADARG, "bpp_stream: bad bounds");
+    if (s->rng != BPP_STREAM_RNG_MT19937 && s->rng != BPP_STREAM_RNG_COUNTER) return fail(BPP_E_BADARG, "bpp_stream: unknown rng");
     return 0;
 }
 
 int bpp_stream_sizes(const bpp_stream *s, int64_t out[2]) {
     if (!s || !out) return fail(BPP_E_BADARG, "bpp_stream_sizes: NULL pointer");
     if (s->num_envs <= 0) return fail(BPP_E_BADARG, "bpp_stream_sizes: bad size");
-    out[0] = (int64_t)(sizeof(bpp_mt) / 4) * s->num_envs;   /* one bpp_mt per bin */
+    /* one bpp_mt per bin, or (counter generator) four words: the bin's 64-bit stream id */
+    out[0] = (int64_t)(s->rng == BPP_STREAM_RNG_COUNTER ? 4 : sizeof(bpp_mt) / 4) * s->num_envs;
     out[1] = 16;                                            /* no scratch needed on the host */
     return 0;
 }
@@ -710,7 +712,12 @@ int bpp_stream_init(const bpp_stream *s, void *stream) {
     if (rc) return rc;
     bpp_mt *rngs = (bpp_mt *)s->mt;
     for (int e = 0; e < s->num_envs; ++e) {
-        bpp_mt_seed(&rngs[e], s->seed0 + (uint64_t)(s->env_id_base + e));
+        if (s->rng == BPP_STREAM_RNG_COUNTER) {
+            const uint64_t sid = (uint64_t)(s->env_id_base + e);
+            s->mt[4 * e] = (uint32_t)sid, s->mt[4 * e + 1] = (uint32_t)(sid >> 32), s->mt[4 * e + 2] = 0, s->mt[4 * e + 3] = 0;
+        } else {
+            bpp_mt_seed(&rngs[e], s->seed0 + (uint64_t)(s->env_id_base + e));
+        }
         s->gen_next[e] = 0;
     }
     return 0;
@@ -731,7 +738,12 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) {
                 row[4 * t + 2] = (uint8_t)s->H;
                 row[4 * t + 3] = 0;
             }
-            int n = bpp_cut2_from_stream(&rngs[e], s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
+            int n;
+            if (s->rng == BPP_STREAM_RNG_COUNTER)       /* a pure function of (seed0, stream id, episode) */
+                n = bpp_cut2_counter(s->seed0, (uint64_t)s->mt[4 * e] | ((uint64_t)s->mt[4 * e + 1] << 32), (uint32_t)s->gen_next[e],
+                                     s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
+            else
+                n = bpp_cut2_from_stream(&rngs[e], s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
             if (n > T - 1 && s->overflow) s->overflow[0] += 1;
             s->gen_next[e] += 1;
         }

@@ -34,7 +34,8 @@ class Stream(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("depth", ctypes.c_int32), ("pool_len", ctypes.c_int32), ("W", ctypes.c_int32),
                 ("L", ctypes.c_int32), ("H", ctypes.c_int32), ("bound_lo", ctypes.c_int32), ("bound_hi", ctypes.c_int32),
                 ("env_id_base", ctypes.c_int64), ("seed0", ctypes.c_uint64), ("ring", ctypes.c_void_p), ("mt", ctypes.c_void_p),
-                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p)]
+                ("work", ctypes.c_void_p), ("gen_next", ctypes.c_void_p), ("state", ctypes.c_void_p), ("overflow", ctypes.c_void_p),
+                ("rng", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
 class StepOut(ctypes.Structure):
@@ -166,7 +167,8 @@ class OracleEnv(object):
             self.overflow = np.zeros(1, np.int32)
             self.stream = Stream(E, D, T, self.W, self.L, self.H, lo, hi, int(env_id_base), int(stream.get("seed", 0)),
                                  _p(self.pool).value, None, None, _p(self.gen_next).value,
-                                 _p(self.state).value, _p(self.overflow).value)
+                                 _p(self.state).value, _p(self.overflow).value,
+                                 {"mt19937": 0, "counter": 1}[stream.get("rng", "mt19937")], 0)
             sizes = (ctypes.c_int64 * 2)()          # the two opaque buffers are sized by the library in use
             _check(lib().bpp_stream_sizes(ctypes.byref(self.stream), sizes))
             self._mt = _aligned_zeros(int(sizes[0]) * 4)

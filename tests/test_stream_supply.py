@@ -48,9 +48,9 @@ def test_emulated_stream_supply_matches_oracle_and_python_random(emu, oracle, si
     spec_check(lambda sz, r, n, base, spec: EmuStreamEnv(emu, sz, r, n, base, spec), oracle, size, rot, E, steps, depth, refill, native)
 
 
-def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native):
+def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native, gen="mt19937"):
     base, seed = 1000, 77
-    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill)
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill, rng=gen)
     env = make_env(size, rot, E, base, spec)
     ref = oracle.OracleEnv(None, size, rot, E, env_id_base=base, env_id_total=base + E + 3, stream=spec)
     obs, mask = env.reset()
@@ -83,8 +83,11 @@ def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native):
     # independent of both native generators: Python's own random.Random through the restatement pinned to the reference
     for e in sorted(set((0, E // 2, E - 1))):
         n_ep = int(rst["episode"][e])
-        rng = random.Random(seed + base + e)
-        seqs = [sequences.cut2_sequence(size, (2, 5), rng) for _ in range(n_ep + 1)]
+        if gen == "counter":    # a sequence is a function of (seed, stream id = global bin id, episode)
+            seqs = [sequences.cut2_sequence(size, (2, 5), sequences.CounterRandom(seed, base + e, k)) for k in range(n_ep + 1)]
+        else:
+            pyrng = random.Random(seed + base + e)
+            seqs = [sequences.cut2_sequence(size, (2, 5), pyrng) for _ in range(n_ep + 1)]
         if not native:
             assert firsts[e] == [s[0] for s in seqs], e                  # every episode played the next sequence of the stream
         cur = int(rst["cursor"][e])
@@ -94,11 +97,11 @@ def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native):
     assert int(rst["episode"].max()) >= 1
 
 
-def knob_check(front, oracle, set_knobs, size, E, depth, steps, pattern, refill=None, seed=7, base=100, fail=0.2):
+def knob_check(front, oracle, set_knobs, size, E, depth, steps, pattern, refill=None, seed=7, base=100, fail=0.2, gen="mt19937"):
     """Fast pipeline (scan / cut / sort) and the one-lane-per-bin kernel are interchangeable refill by refill: `pattern(t)`
     chooses which one serves lock-step t.  Everything a step returns and, at the end, the whole ring must equal the
     oracle's (its generator is the plain-C one of include/bpp_gen.inl)."""
-    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill or max(1, depth - 3))
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill or max(1, depth - 3), rng=gen)
     set_knobs(stream_legacy=pattern(0))
     try:
         env = front(size, E, base, spec)
