@@ -96,7 +96,13 @@ typedef struct bpp_batch {
                               four job-level sums (main.py:159-162) are bit-reproducible             */
     int32_t pool_mode;     /* BPP_POOL_STATIC: the row rule above.  BPP_POOL_RING: seq_pool is the ring of a
                               bpp_stream, pool_size = depth * num_envs, episode k of LOCAL bin e plays row
-                              (k mod depth) * num_envs + e, refilled by bpp_stream_refill                */
+                              (k mod depth) * num_envs + e, refilled by bpp_stream_refill.  A ring row starts
+                              with TWO LOOK-AHEAD ENTRIES -- item 1 of the bin's NEXT row and item 0 of the row
+                              after that, copied there when those rows are cut -- and holds item i at entry
+                              2 + i (pool_len counts all entries): what a step fetches ahead for both outcomes
+                              (the item two places on; the first items of the next two episodes,
+                              binCreator.py:15-18) then comes from the ONE row it is reading anyway instead
+                              of three rows scattered over a ring far larger than the caches               */
     int32_t reserved0;
 } bpp_batch;
 
@@ -109,9 +115,10 @@ typedef struct bpp_batch {
  * the bin plays the k-th sequence that stream yields through the reference creator.  `ring` holds `depth` rows per
  * bin; bpp_stream_refill cuts new sequences into the rows of episodes the bin has finished, so that `depth`
  * episodes are available from the current one.  A step reads rows up to two episodes ahead and a bin can finish at
- * most one episode per step: refill at least every depth - 3 lock-steps.  Rows are padded with the terminator
- * (W,L,H); a sequence longer than pool_len - 1 is truncated and counted in `overflow` (size pool_len as
- * W*L*H / bound_lo^3 + 1 to make that impossible -- with rows that long, at most 2048 entries, the refill is the
+ * most one episode per step: refill at least every depth - 3 lock-steps.  Rows are two look-ahead entries (see
+ * bpp_batch.pool_mode) followed by the items, padded with the terminator (W,L,H); a sequence longer than pool_len - 3 is
+ * truncated and counted in `overflow` (size pool_len as
+ * W*L*H / bound_lo^3 + 3 to make that impossible -- with rows that long, at most 2048 entries, the refill is the
  * four-kernel pipeline scan / pretwist / cut / sort of csrc/bpp_stream_gen.inl, else one lane per bin).
  * `mt` and `work` are opaque; bpp_stream_sizes tells how large they must be (both 16-byte aligned).  `mt` is an
  * array of num_envs equal records, one per bin (copy a bin's record together with its ring rows and gen_next to

@@ -38,6 +38,15 @@
 
 #pragma clang fp contract(off)  // float64 reward / return sums must round exactly like numpy
 
+// Where the three pool entries are that the NEXT step may need (binCreator.py:15-18 look-ahead; fetched speculatively for
+// both outcomes): item cursor + 2 of the current row, item 1 of the next row, item 0 of the row after that.  A static
+// pool: three rows.  The ring of a stream (ring2 == 2): the two entries of the rows behind have been copied into the
+// FIRST TWO ENTRIES of the current row when those rows were cut (include/bpp_abi.h), so that all three come from the
+// current row -- from ONE line while the cursor is below 28.  (A step's three random HBM reads per bin cost 6 us per
+// lock-step of 65 536 bins once pool or ring no longer fit the caches: profiles/r4h_step_kernel_vs_pool_size.json.)
+struct LookAheadAt {
+    size_t ok, f1, f2;
+};
 // Profiling aid, compiled in only with -DBPP_ENABLE_ABLATION (tools/build_variant.sh abl -DBPP_ENABLE_ABLATION): BPP_ABLATE=<bit mask>
 // then skips individual phases so their cost can be read off rocprofv3 (results are wrong when used).
 #ifdef BPP_ENABLE_ABLATION
@@ -90,6 +99,7 @@ struct Params {
     FastDiv divW, divM4, divPWW;      // runtime-geometry fast path: by W, M/4 and (L+1)+W
     // sequences
     int32_t P, T, seq_stride, base_mod;  // seq_stride = env_id_total % P, base_mod = env_id_base % P
+    int32_t ring2;         // 2 for the ring of a stream (rows start with two look-ahead entries, item i at entry 2 + i), else 0
     double binvol;
     const uint32_t *pool;  // [P][T] packed x | y<<8 | z<<16
     // state
@@ -117,6 +127,16 @@ struct Params {
     uint64_t sample_seed, sample_step;
     int64_t env_id_base;
 };
+
+__device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, int seq_n, int seq_nn, int cursor) {
+    const int T = p.T, r2 = p.ring2;
+    const bool ring = r2 != 0;
+    LookAheadAt a;
+    a.ok = (size_t)seq * T + r2 + min(cursor + 2, T - 1 - r2);
+    a.f1 = (size_t)(ring ? seq : seq_n) * T + (ring ? 0 : min(1, T - 1));
+    a.f2 = (size_t)(ring ? seq : seq_nn) * T + (ring ? 1 : 0);
+    return a;
+}
 
 // Episode statistics (main.py:159-162): every bin owns one row [return sum, final-ratio sum, length sum, episodes] of
 // bpp_batch.ep_acc and the lane that decides the bin adds a finished episode to it with a plain read-modify-write.
@@ -308,9 +328,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             int seq_nn = seq_n + p.seq_stride;
             seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
             const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-            const uint32_t sp_ok = p.pool[(size_t)st.seq * T + min(st.cursor + 2, T - 1)];
-            const uint32_t sp_f1 = p.pool[(size_t)seq_n * T + min(1, T - 1)];
-            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
+            const LookAheadAt la = look_ahead_at(p, st.seq, seq_n, seq_nn, st.cursor);
+            const uint32_t sp_ok = p.pool[la.ok], sp_f1 = p.pool[la.f1], sp_f2 = p.pool[la.f2];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             // bin3D.py:96-105: rotated iff idx > area (strict)
             const bool noop = act == BPP_ACTION_NOOP;   // include/bpp_abi.h: the bin is left alone
@@ -395,9 +414,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.ep_len = 0;
             int sn = st.seq + p.seq_stride;
             sn = sn >= p.P ? sn - p.P : sn;
-            st.item_cur = p.pool[(size_t)st.seq * p.T];
-            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
-            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.item_cur = p.pool[(size_t)st.seq * p.T + p.ring2];
+            st.item_next = p.pool[(size_t)st.seq * p.T + p.ring2 + min(1, p.T - 1 - p.ring2)];
+            st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
             st.hmax = 0;
             p.state[e] = st;
             r.item = st.item_cur;
@@ -842,9 +861,8 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             int seq_nn = seq_n + p.seq_stride;
             seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
             const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-            const uint32_t sp_ok = p.pool[(size_t)st.seq * T + min(st.cursor + 2, T - 1)];
-            const uint32_t sp_f1 = p.pool[(size_t)seq_n * T + min(1, T - 1)];
-            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * T];
+            const LookAheadAt la = look_ahead_at(p, st.seq, seq_n, seq_nn, st.cursor);
+            const uint32_t sp_ok = p.pool[la.ok], sp_f1 = p.pool[la.f1], sp_f2 = p.pool[la.f2];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
@@ -962,9 +980,9 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             st.ep_len = 0;
             int sn = st.seq + p.seq_stride;
             sn = sn >= p.P ? sn - p.P : sn;
-            st.item_cur = p.pool[(size_t)st.seq * p.T];
-            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
-            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.item_cur = p.pool[(size_t)st.seq * p.T + p.ring2];
+            st.item_next = p.pool[(size_t)st.seq * p.T + p.ring2 + min(1, p.T - 1 - p.ring2)];
+            st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
             st.hmax = 0;
             if (active) p.state[e] = st;
             r.item = st.item_cur;
@@ -2145,10 +2163,13 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     if (b->pool_mode == BPP_POOL_RING) {   // ring of a bpp_stream: row = (episode mod depth) * num_envs + local bin
         if (b->pool_size % b->num_envs != 0 || b->pool_size / b->num_envs < 4)
             return fail(BPP_E_BADARG, "bpp_batch: a ring pool holds depth * num_envs rows, depth >= 4");
+        if (b->pool_len < 4) return fail(BPP_E_BADARG, "bpp_batch: ring rows hold two look-ahead entries, at least one item and the terminator");
         p.seq_stride = b->num_envs % b->pool_size;
+        p.ring2 = 2;
         p.base_mod = 0;
     } else if (b->pool_mode == BPP_POOL_STATIC) {
         p.seq_stride = (int32_t)(b->env_id_total % b->pool_size);
+        p.ring2 = 0;
         p.base_mod = (int32_t)(b->env_id_base % b->pool_size);
     } else {
         return fail(BPP_E_BADARG, "bpp_batch: unknown pool_mode");
@@ -2563,8 +2584,8 @@ SideStream *side_stream() {
 
 int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
-    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0)
-        return fail(BPP_E_BADARG, "bpp_stream: need num_envs > 0, depth >= 4, pool_len >= 2");
+    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 4 || s->env_id_base < 0)
+        return fail(BPP_E_BADARG, "bpp_stream: need num_envs > 0, depth >= 4, pool_len >= 4 (two look-ahead entries, an item, the terminator)");
     if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi))
         return fail(BPP_E_BADARG, "bpp_stream: bin / bounds the reference generator cannot cut");
     if (((uintptr_t)s->ring & 3u) || ((uintptr_t)s->work & 15u) || ((uintptr_t)s->mt & 15u))
@@ -2597,7 +2618,7 @@ StreamPlan plan_stream(const bpp_stream *s) {
     p.legacy_bytes = (size_t)stream_work_entries(s->W, s->L, s->H, s->bound_lo) * E * 8;
     p.cut_lds = (size_t)stream_cut_lds_bytes(p.cap, p.fb);
     p.sort_lds = (size_t)4 * (s->pool_len + 256) * 4;
-    p.fast = s->pool_len - 1 >= p.maxn && s->pool_len <= kSortMaxT && p.cut_lds <= 64 * 1024 && p.sort_lds <= 64 * 1024;
+    p.fast = s->pool_len - 1 - kRowHdr >= p.maxn && s->pool_len <= kSortMaxT && p.cut_lds <= 64 * 1024 && p.sort_lds <= 64 * 1024;
     return p;
 }
 }  // namespace

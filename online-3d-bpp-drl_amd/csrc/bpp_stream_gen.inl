@@ -285,6 +285,8 @@ struct StreamWork {        // views into bpp_stream.work (see plan_stream)
     int32_t kmax, urgent;  // kmax > 0: a bin gets at most kmax sequences per refill unless that leaves it fewer than
                            // `urgent` rows from its current episode (then as many as it takes); 0: always all depth rows
 };
+constexpr int kRowHdr = 2;             // entries in front of a ring row's items (include/bpp_abi.h): item 1 of the NEXT row and
+                                       // item 0 of the row after it -- the look-ahead a step needs, in the line it reads anyway
 constexpr int kOutRing = 64;           // output BYTES a lane holds in LDS, its own contiguous run of kRingStride bytes:
                                        // position p of the job's output sequence at byte p % 64, the first kCand bytes
                                        // repeated behind byte 63 so that kCand consecutive outputs are consecutive bytes
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
     bool active = job && need > 0;
     const bool ran = active;
     const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << FB) | ((uint32_t)s.H << (2 * FB));
-    CutLane c{whole, 1u, 0, 0, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T, 0};
+    CutLane c{whole, 1u, 0, 0, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T + kRowHdr, 0};
     if (active) col.set(0u, whole);
     int filled = 0;                                                  // outputs put into the ring since the job started (a multiple of 4)
 
@@ -769,10 +771,10 @@ __global__ __launch_bounds__(64) void stream_cut_kernel(bpp_stream s, StreamWork
             finished = cut_visit_lds<FB>(c, col, cap, ringb, filled, active ? ~0u : 0u, lo, hi) != 0u;
         }
         if (finished) {
-            c.row[T - 1] = (uint32_t)c.nv;            // length for the sort kernel (which restores the terminator)
+            c.row[T - 1 - kRowHdr] = (uint32_t)c.nv;  // (the row's last entry) length for the sort kernel, which restores the terminator
             ++g;
             if (--need > 0) {
-                c.row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+                c.row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T + kRowHdr;
                 pend.set(c.side, 0, whole);
                 c.tail_a = 1;
                 c.nv = 0;
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(64) void stream_cut_ctr_kernel(bpp_stream s, Stream
     bool active = job && need > 0;
     const bool ran = active;
     const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << FB) | ((uint32_t)s.H << (2 * FB));
-    CtrLane c{whole, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T, CtrRng::key(s.seed0, sid, (uint32_t)g)};
+    CtrLane c{whole, 0, 1, 0, 0, 0, (uint32_t *)s.ring + ((size_t)(active ? g % D : 0) * E + e) * T + kRowHdr, CtrRng::key(s.seed0, sid, (uint32_t)g)};
     if (active) col.set(0u, whole);
     while (__ballot(active)) {
         bool finished;
@@ -958,10 +960,10 @@ __global__ __launch_bounds__(64) void stream_cut_ctr_kernel(bpp_stream s, Stream
             finished = cut_visit_ctr<FB>(c, col, cap, active ? ~0u : 0u, lo, hi) != 0u;
         }
         if (finished) {
-            c.row[T - 1] = (uint32_t)c.nv;            // length for the sort kernel (which restores the terminator)
+            c.row[T - 1 - kRowHdr] = (uint32_t)c.nv;  // (the row's last entry) length for the sort kernel, which restores the terminator
             ++g;
             if (--need > 0) {
-                c.row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
+                c.row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T + kRowHdr;
                 pend.set(c.side, 0, whole);
                 c.tail_a = 1;
                 c.nv = 0;
@@ -984,6 +986,7 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = s.num_envs, T = s.pool_len, D = s.depth;
+    const int TI = T - kRowHdr;                       // entries of a row behind its look-ahead header
     uint32_t *ent = (uint32_t *)smem + (size_t)wave * (T + 256);
     int *lvl = (int *)(ent + T);                      // per base height: count, then first free position
     const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
@@ -991,23 +994,31 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
     const int nrows = w.hdr[3], stride = gridDim.x * 4;
     int q = blockIdx.x * 4 + wave;                    // wave-uniform
     if (q >= nrows) return;
-    auto row_of = [&](int k) {
-        const int64_t id = w.rows[k];
-        return (uint32_t *)s.ring + ((size_t)((int)(id >> 32) % D) * E + (int)(uint32_t)id) * T;
-    };
+    auto base_of = [&](int bin, int episode) { return (uint32_t *)s.ring + ((size_t)(episode % D) * E + bin) * T; };
     const int fb = w.fb;
-    uint32_t *row = row_of(q);
-    uint32_t mine = lane < T - 1 ? cut_box_bytes(row[lane], fb) : 0u;    // this lane's box if the row is short, and the row's length
-    int nv = (int)row[T - 1];
+    int64_t id = w.rows[q];
+    uint32_t *row = base_of((int)(uint32_t)id, (int)(id >> 32)) + kRowHdr;
+    uint32_t mine = lane < TI - 1 ? cut_box_bytes(row[lane], fb) : 0u;    // this lane's box if the row is short, and the row's length
+    int nv = (int)row[TI - 1];
     for (;;) {
         const int qn = q + stride;
+        int64_t idn = id;
         uint32_t *rown = row;
         uint32_t minen = 0;
         int nvn = 0;
         if (qn < nrows) {                             // next row: loads in flight while this one is ranked
-            rown = row_of(qn);
-            minen = lane < T - 1 ? cut_box_bytes(rown[lane], fb) : 0u;
-            nvn = (int)rown[T - 1];
+            idn = w.rows[qn];
+            rown = base_of((int)(uint32_t)idn, (int)(idn >> 32)) + kRowHdr;
+            minen = lane < TI - 1 ? cut_box_bytes(rown[lane], fb) : 0u;
+            nvn = (int)rown[TI - 1];
+        }
+        // the look-ahead copies of this row's first two items (terminators where the row is shorter): item 1 goes into entry
+        // 0 of the row BEFORE this one, item 0 into entry 1 of the row two before -- written by the lanes that place them
+        const int bin = (int)(uint32_t)id, ep = (int)(id >> 32);
+        uint32_t *hdr1 = ep >= 1 ? base_of(bin, ep - 1) : nullptr, *hdr0 = ep >= 2 ? base_of(bin, ep - 2) + 1 : nullptr;
+        if (lane == 0) {
+            if (nv < 2 && hdr1) *hdr1 = term;
+            if (nv < 1 && hdr0) *hdr0 = term;
         }
         if (nv <= 64) {
             const bool valid = lane < nv;
@@ -1021,7 +1032,12 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
                 place += key > lv ? __popcll(m) : (key == lv ? __popcll(m & below) : 0);
                 todo &= ~m;
             }
-            if (valid) row[place] = mine & 0x00ffffffu;
+            if (valid) {
+                const uint32_t v = mine & 0x00ffffffu;
+                row[place] = v;
+                if (place == 0 && hdr0) *hdr0 = v;
+                if (place == 1 && hdr1) *hdr1 = v;
+            }
         } else {
             wave_sync();
             for (int k = lane; k < 256; k += 64) lvl[k] = 0;
@@ -1062,12 +1078,18 @@ __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWo
                     wave_sync();
                     todo &= ~m;
                 }
-                if (valid) row[dest] = val & 0x00ffffffu;
+                if (valid) {
+                    const uint32_t v = val & 0x00ffffffu;
+                    row[dest] = v;
+                    if (dest == 0 && hdr0) *hdr0 = v;
+                    if (dest == 1 && hdr1) *hdr1 = v;
+                }
             }
         }
-        for (int k = nv + lane; k < T; k += 64) row[k] = term;
+        for (int k = nv + lane; k < TI; k += 64) row[k] = term;
         if (qn >= nrows) break;
         q = qn;
+        id = idn;
         row = rown;
         mine = minen;
         nv = nvn;
@@ -1195,6 +1217,20 @@ __global__ __launch_bounds__(256) void stream_init_kernel(bpp_stream s) {
     s.gen_next[e] = 0;
 }
 
+// The plain kernel's hand-over of one cut sequence (`n` boxes in `vals`, sorted) to ring row `g` of bin `e`: items behind
+// the two look-ahead entries, terminator padding, and this row's first two items into the headers of the two rows before.
+__device__ __forceinline__ int stream_store_row(const bpp_stream &s, int e, int g, const LdsVals &vals, int n, uint32_t term) {
+    const int E = s.num_envs, T = s.pool_len, D = s.depth, TI = T - kRowHdr;
+    uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T + kRowHdr;
+    const int nw = n < TI - 1 ? n : TI - 1;
+    for (int t = 0; t < nw; ++t) row[t] = vals.get(t) & 0x00ffffffu;   // drop the sort key
+    for (int t = nw; t < TI; ++t) row[t] = term;                        // pad with the terminator (last entry always)
+    const uint32_t i0 = nw > 0 ? vals.get(0) & 0x00ffffffu : term, i1 = nw > 1 ? vals.get(1) & 0x00ffffffu : term;
+    if (g >= 1) ((uint32_t *)s.ring + ((size_t)((g - 1) % D) * E + e) * T)[0] = i1;
+    if (g >= 2) ((uint32_t *)s.ring + ((size_t)((g - 2) % D) * E + e) * T)[1] = i0;
+    return n > TI - 1;
+}
+
 // One lane per bin: cut new sequences into the ring until the bin has `depth` episodes available from its current
 // one (rows of episodes the bin has finished are the ones overwritten).
 __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream s) {
@@ -1203,7 +1239,8 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
     const int lane = threadIdx.x;
     const int e = blockIdx.x * kStreamLanes + lane;
     if (e >= s.num_envs) return;     // no workgroup-level synchronisation below
-    const int E = s.num_envs, T = s.pool_len, D = s.depth;
+    const int E = s.num_envs, D = s.depth;
+    const int T = s.pool_len;
     const int cur = s.state[e].episode;
     int g = s.gen_next[e];
     if (g >= cur + D) return;
@@ -1214,14 +1251,11 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
         const uint32_t *rc = s.mt + (size_t)e * kCtrRec;
         const uint64_t sid = (uint64_t)rc[0] | ((uint64_t)rc[1] << 32);
         while (g < cur + D) {
-            uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
-            LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1};
+            uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T + kRowHdr;
+            LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1 - kRowHdr};
             CtrRng rng = CtrRng::key(s.seed0, sid, (uint32_t)g);
             const int n = cut2_generate(rng, work, vals, s.W, s.L, s.H, s.bound_lo, s.bound_hi);
-            over += n > T - 1;
-            const int nw = n < T - 1 ? n : T - 1;
-            for (int t = 0; t < nw; ++t) row[t] = vals.get(t) & 0x00ffffffu;
-            for (int t = nw; t < T; ++t) row[t] = term;
+            over += stream_store_row(s, e, g, vals, n, term);
             ++g;
         }
         s.gen_next[e] = g;
@@ -1233,13 +1267,10 @@ __global__ __launch_bounds__(kStreamLanes) void stream_refill_kernel(bpp_stream 
     BufferedMT rng{rec, rec + kMtRaw + par0 * kMtHalf, lds + (2 * kStreamPendCap + kStreamValCap) * kStreamLanes + lane,
                    (int)rec[kMtPos], 0, 0, par0, rec[kMtNextOk]};
     while (g < cur + D) {
-        uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T;
-        LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1};
+        uint32_t *row = (uint32_t *)s.ring + ((size_t)(g % D) * E + e) * T + kRowHdr;
+        LdsVals vals{lds + (2 * kStreamPendCap) * kStreamLanes + lane, row, T - 1 - kRowHdr};
         const int n = cut2_generate(rng, work, vals, s.W, s.L, s.H, s.bound_lo, s.bound_hi);
-        over += n > T - 1;
-        const int nw = n < T - 1 ? n : T - 1;
-        for (int t = 0; t < nw; ++t) row[t] = vals.get(t) & 0x00ffffffu;   // drop the sort key
-        for (int t = nw; t < T; ++t) row[t] = term;                        // pad with the terminator (last entry always)
+        over += stream_store_row(s, e, g, vals, n, term);
         ++g;
     }
     rec[kMtPos] = (uint32_t)(rng.idx - (rng.have - rng.pos));             // buffered but unused outputs are handed out again

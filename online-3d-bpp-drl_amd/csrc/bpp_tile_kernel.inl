@@ -240,15 +240,13 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             const int64_t act = act0;
             // binCreator.py:15-18: current / next / first-of-next-episode items come from the state record;
             // the pool entries the NEXT step needs are fetched speculatively for both outcomes.
-            const int Tn = p.T;
             int seq_n = st.seq + p.seq_stride;
             seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
             int seq_nn = seq_n + p.seq_stride;
             seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
             const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-            const uint32_t sp_ok = p.pool[(size_t)st.seq * Tn + min(st.cursor + 2, Tn - 1)];
-            const uint32_t sp_f1 = p.pool[(size_t)seq_n * Tn + min(1, Tn - 1)];
-            const uint32_t sp_f2 = p.pool[(size_t)seq_nn * Tn];
+            const LookAheadAt la = look_ahead_at(p, st.seq, seq_n, seq_nn, st.cursor);
+            const uint32_t sp_ok = p.pool[la.ok], sp_f1 = p.pool[la.f1], sp_f2 = p.pool[la.f2];
             const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
             const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
             int64_t idx = act;                                         // bin3D.py:96-105
@@ -373,9 +371,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) void bpp_tile_kernel(const Para
             st.ep_len = 0;
             int sn = st.seq + p.seq_stride;
             sn = sn >= p.P ? sn - p.P : sn;
-            st.item_cur = p.pool[(size_t)st.seq * p.T];
-            st.item_next = p.pool[(size_t)st.seq * p.T + min(1, p.T - 1)];
-            st.item_reset = p.pool[(size_t)sn * p.T];
+            st.item_cur = p.pool[(size_t)st.seq * p.T + p.ring2];
+            st.item_next = p.pool[(size_t)st.seq * p.T + p.ring2 + min(1, p.T - 1 - p.ring2)];
+            st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
             st.hmax = 0;
             if (lead) p.state[e] = st;
             r.item = st.item_cur;

@@ -253,8 +253,8 @@ class BppVecEnv(object):
                     rng="counter": the same cutting algorithm on a counter-based generator (distribution parity,
                     SURVEY 8f2's bar; no per-bin state, no regeneration kernel -- the fast supply).  The ring
                     is refilled every R <= D - 3 lock-steps (default D = 8, R = 5); `rollout_uniform` runs the
-                    refills beside the lock-steps when D >= 2 R + 3 (e.g. D = 32, R = 14).  Costs 11 KB of
-                    generator state per bin plus D rows of W*L*H / lo^3 + 1 entries.
+                    refills beside the lock-steps when D >= 2 R + 3 (e.g. D = 32, R = 14).  Costs 6.6 KB of
+                    generator state per bin (16 bytes with rng="counter") plus D rows of W*L*H / lo^3 + 3 entries.
     """
 
     def __init__(self, num_envs, container_size=(10, 10, 10), enable_rotation=False, pool=None, device="cuda",
@@ -300,7 +300,8 @@ class BppVecEnv(object):
                 depth = int(stream.get("depth", 8))
                 if depth < 4:
                     raise ValueError("stream depth must be >= 4")
-                pool_len = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 1))
+                # entries per ring row: two look-ahead entries (include/bpp_abi.h), the longest possible sequence, the terminator
+                pool_len = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3))
                 self.refill_every = int(stream.get("refill_every", depth - 3))
                 if not 1 <= self.refill_every <= depth - 3:
                     raise ValueError("refill_every must be in 1 .. depth - 3")
@@ -781,7 +782,8 @@ class BppVecEnv(object):
         st = self.state
         cursor, seq = st[:, 0].long(), st[:, 7].long()
         T = self.pool.shape[1]
-        idx = torch.clamp(cursor.unsqueeze(1) + torch.arange(int(k), device=self.device).unsqueeze(0), max=T - 1)
+        hdr = 2 if self._stream is not None else 0       # ring rows start with two look-ahead entries (include/bpp_abi.h)
+        idx = hdr + torch.clamp(cursor.unsqueeze(1) + torch.arange(int(k), device=self.device).unsqueeze(0), max=T - 1 - hdr)
         return self.pool[seq.unsqueeze(1), idx][:, :, :3].to(torch.int32)
 
     def heightmaps(self):

@@ -149,6 +149,7 @@ static int check_batch(const bpp_batch *b) {
     if (b->pool_mode != BPP_POOL_STATIC && b->pool_mode != BPP_POOL_RING) return fail(BPP_E_BADARG, "bpp_batch: unknown pool_mode");
     if (b->pool_mode == BPP_POOL_RING && (b->pool_size % b->num_envs != 0 || b->pool_size / b->num_envs < 4))
         return fail(BPP_E_BADARG, "bpp_batch: a ring pool holds depth * num_envs rows, depth >= 4");
+    if (b->pool_mode == BPP_POOL_RING && b->pool_len < 4) return fail(BPP_E_BADARG, "bpp_batch: ring rows need pool_len >= 4");
     return 0;
 }
 
@@ -182,7 +183,12 @@ static void next_box(const bpp_batch *b, int e, const bpp_env_state *s, int item
 
 /* Keep the pool-entry cache of the state record coherent (see include/bpp_abi.h). */
 static uint32_t pool_entry(const bpp_batch *b, int64_t seq, int c) {
-    if (c > b->pool_len - 1) c = b->pool_len - 1;
+    /* item c of row seq.  The rows of a stream's ring start with two look-ahead entries (include/bpp_abi.h) that this
+       library writes but never reads: it looks the following rows up directly -- which is what checks the kernels'
+       use of those entries. */
+    const int hdr = b->pool_mode == BPP_POOL_RING ? 2 : 0;
+    if (c > b->pool_len - 1 - hdr) c = b->pool_len - 1 - hdr;
+    c += hdr;
     const uint8_t *p = b->seq_pool + ((size_t)seq * b->pool_len + c) * 4;
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
@@ -691,7 +697,7 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
  * opaque, 625 words per bin either way), sequences drawn one after the other with include/bpp_gen.inl ---------- */
 static int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
-    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 2 || s->env_id_base < 0) return fail(BPP_E_BADARG, "bpp_stream: bad size");
+    if (s->num_envs <= 0 || s->depth < 4 || s->pool_len < 4 || s->env_id_base < 0) return fail(BPP_E_BADARG, "bpp_stream: bad size");
     if (!bpp_gen_cut2_args_ok(1, s->pool_len, s->W, s->L, s->H, s->bound_lo, s->bound_hi)) return fail(BPP_E_BADARG, "bpp_stream: bad bounds");
     if (s->rng != BPP_STREAM_RNG_MT19937 && s->rng != BPP_STREAM_RNG_COUNTER) return fail(BPP_E_BADARG, "bpp_stream: unknown rng");
     return 0;
@@ -731,8 +737,10 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) {
     const int E = s->num_envs, T = s->pool_len, D = s->depth;
     for (int e = 0; e < E; ++e) {
         while (s->gen_next[e] < s->state[e].episode + D) {
-            uint8_t *row = s->ring + ((size_t)(s->gen_next[e] % D) * E + e) * T * 4;
-            for (int t = 0; t < T; ++t) {
+            const int g = s->gen_next[e];
+            uint8_t *base = s->ring + ((size_t)(g % D) * E + e) * T * 4;
+            uint8_t *row = base + 2 * 4;                  /* items behind the two look-ahead entries */
+            for (int t = 0; t < T - 2; ++t) {
                 row[4 * t] = (uint8_t)s->W;
                 row[4 * t + 1] = (uint8_t)s->L;
                 row[4 * t + 2] = (uint8_t)s->H;
@@ -740,11 +748,14 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) {
             }
             int n;
             if (s->rng == BPP_STREAM_RNG_COUNTER)       /* a pure function of (seed0, stream id, episode) */
-                n = bpp_cut2_counter(s->seed0, (uint64_t)s->mt[4 * e] | ((uint64_t)s->mt[4 * e + 1] << 32), (uint32_t)s->gen_next[e],
-                                     s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
+                n = bpp_cut2_counter(s->seed0, (uint64_t)s->mt[4 * e] | ((uint64_t)s->mt[4 * e + 1] << 32), (uint32_t)g,
+                                     s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 3);
             else
-                n = bpp_cut2_from_stream(&rngs[e], s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 1);
-            if (n > T - 1 && s->overflow) s->overflow[0] += 1;
+                n = bpp_cut2_from_stream(&rngs[e], s->W, s->L, s->H, s->bound_lo, s->bound_hi, row, T - 3);
+            if (n > T - 3 && s->overflow) s->overflow[0] += 1;
+            /* this row's item 1 -> entry 0 of the row before, its item 0 -> entry 1 of the row two before */
+            if (g >= 1) memcpy(s->ring + ((size_t)((g - 1) % D) * E + e) * T * 4, row + 4, 4);
+            if (g >= 2) memcpy(s->ring + ((size_t)((g - 2) % D) * E + e) * T * 4 + 4, row, 4);
             s->gen_next[e] += 1;
         }
     }

@@ -141,7 +141,7 @@ class OracleEnv(object):
         if stream is not None:
             lo, hi = (int(v) for v in stream.get("bound", (2, 5)))
             D = int(stream.get("depth", 8))
-            T = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 1))
+            T = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3))   # 2 look-ahead entries + items + terminator
             pool = np.zeros((D * int(num_envs), T, 4), np.uint8)
         self.pool = np.ascontiguousarray(pool, dtype=np.uint8)
         assert self.pool.ndim == 3 and self.pool.shape[2] == 4

@@ -24,8 +24,14 @@ def test_counter_random_is_what_the_oracle_library_cuts(oracle):
     for e in range(E):
         for k in range(D):
             want = sequences.cut2_sequence(size, (2, 5), sequences.CounterRandom(seed, base + e, k))
-            row = [tuple(int(v) for v in it[:3]) for it in ring[k, e]]
+            row = [tuple(int(v) for v in it[:3]) for it in ring[k, e][2:]]      # (behind the two look-ahead entries)
             assert row[:len(want)] == want and all(it == size for it in row[len(want):]), (e, k)
+            nxt = sequences.cut2_sequence(size, (2, 5), sequences.CounterRandom(seed, base + e, k + 1))
+            nn = sequences.cut2_sequence(size, (2, 5), sequences.CounterRandom(seed, base + e, k + 2))
+            if k + 1 < D:   # the look-ahead entries: item 1 of the next row, item 0 of the row after (cut so far: rows 0 .. D - 1)
+                assert tuple(int(v) for v in ring[k, e][0][:3]) == nxt[1]
+            if k + 2 < D:
+                assert tuple(int(v) for v in ring[k, e][1][:3]) == nn[0]
     r = sequences.CounterRandom(5, 7, 0)
     draws = np.array([r.below(7) for _ in range(70000)])
     assert set(draws) == set(range(7)) and abs(np.bincount(draws) / 10000.0 - 1.0).max() < 0.04
