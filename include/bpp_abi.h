@@ -334,7 +334,8 @@ int bpp_wait(void *stream);
  *     float64 ep_ret[n] (Monitor's `r` before round(., 6)); float64 ratio[n]; int32 ep_len[n] (Monitor's `l`);
  *     int32 counter[n] (boxes placed); int32 bin[n] (local bin numbers);
  * then the first BPP_FINISHED_BYTES(n) bytes are copied to `host` (page-locked) and the stream is synchronised: only what
- * is needed crosses PCIe, in one transfer, already laid out as the arrays a caller wants.  count != n (the caller's `done`
+ * is needed crosses PCIe, in one transfer, already laid out as the arrays a caller wants.  dev == NULL: `host` is
+ * page-locked memory MAPPED into the device and the kernel writes header and arrays there itself (no staging copy).  count != n (the caller's `done`
  * belongs to another step): BPP_E_BADARG.  Blocks the calling thread like bpp_fetch_to_host. */
 #define BPP_FINISHED_BYTES(n) (32 + 28 * (int64_t)(n) + 4)      /* (+ 4: room for the 8-byte alignment of nothing -- n may be odd) */
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,

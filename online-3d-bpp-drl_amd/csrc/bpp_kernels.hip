@@ -2504,15 +2504,19 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
 
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
-    if (!done || !ep_ret || !ratio || !ep_len || !counter || !dev || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
     if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
     if (((uintptr_t)dev & 7u) || ((uintptr_t)host & 7u)) return fail(BPP_E_BADARG, "bpp_gather_finished: buffers must be 8-byte aligned");
+    // dev == NULL: `host` is page-locked memory mapped into the device and the kernel writes the arrays there itself
+    // (~200 KB of mostly consecutive stores at 65 536 bins) -- no staging buffer, no copy engine
     hipLaunchKernelGGL(compact_finished_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
-                       (unsigned char *)dev, n);
+                       (unsigned char *)(dev ? dev : host), n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    e = hipMemcpyAsync(host, dev, (size_t)BPP_FINISHED_BYTES(n), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
+    if (dev) {
+        e = hipMemcpyAsync(host, dev, (size_t)BPP_FINISHED_BYTES(n), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
+    }
     e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     if (*(const int32_t *)host != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");

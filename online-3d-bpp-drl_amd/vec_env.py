@@ -473,12 +473,12 @@ class BppVecEnv(object):
         if st is None:
             nb = (32 + 28 * self.E + 4 + 7) // 8 * 8
             t = torch.empty((nb,), dtype=torch.uint8).pin_memory()
-            st = self._fin_stage = (t, t.numpy(), torch.empty((nb,), dtype=torch.uint8, device=self.device))
-        _, host, dev = st
+            st = self._fin_stage = (t, t.numpy())
+        _, host = st
         base, lay = res._flat.data_ptr(), res._layout
         self._on_device()
         _lib.check(self.lib.bpp_gather_finished(base + lay["done"][0], base + lay["ep_ret"][0], base + lay["ratio"][0],
-                                                base + lay["ep_len"][0], base + lay["counter"][0], self.E, dev.data_ptr(),
+                                                base + lay["ep_len"][0], base + lay["counter"][0], self.E, None,
                                                 host.ctypes.data, int(n), self._stream_ptr()))
         buf = host[32:32 + 28 * n].copy()
         return (buf[24 * n:28 * n].view("<i4"), buf[:8 * n].view("<f8"), buf[8 * n:16 * n].view("<f8"),

@@ -475,8 +475,9 @@ int bpp_episode_acc_reduce(double *ep_acc, int32_t E, double *acc, int32_t clear
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
     (void)stream;
-    if (!done || !ep_ret || !ratio || !ep_len || !counter || !dev || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
+    if (!done || !ep_ret || !ratio || !ep_len || !counter || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
     if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    if (!dev) dev = host;
     unsigned char *out = (unsigned char *)dev;
     double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
     int32_t *o_len = (int32_t *)(o_ratio + n), *o_cnt = o_len + n, *o_bin = o_cnt + n;
@@ -488,7 +489,7 @@ int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double 
         }
     memset(out, 0, 32);
     *(int32_t *)out = k;
-    memmove(host, dev, (size_t)BPP_FINISHED_BYTES(n));
+    if (dev != host) memmove(host, dev, (size_t)BPP_FINISHED_BYTES(n));
     if (k != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
     return 0;
 }
