@@ -1,5 +1,6 @@
 """Long soak of the endless device supply on the GPU against the oracle (tools, not part of the suite: ~40 s on the box):
-thousands of lock-steps per bin, i.e. hundreds of sequences and dozens of laps of every bin's MT19937 state; every output of
+thousands of lock-steps per bin, i.e. hundreds of sequences and dozens of laps of every bin's MT19937 state, for both generators
+(argv: mt19937 / counter); every output of
 the last step, all state records and the generators' progress must equal the oracle's, the items shown Python's `random`."""
 import sys, time
 import os
@@ -26,9 +27,11 @@ class Env(object):
     def state_records(self):
         assert int(self.env.stream_overflow.item()) == 0; return self.env.state_numpy()
 
-for (size, rot, E, steps, depth, refill, native) in [((10,10,10), False, 4096, 2000, 16, 6, True), ((10,10,10), True, 3000, 1500, 32, 14, True),
+gens = sys.argv[1:] or ["mt19937", "counter"]
+for gen in gens:
+  for (size, rot, E, steps, depth, refill, native) in [((10,10,10), False, 4096, 2000, 16, 6, True), ((10,10,10), True, 3000, 1500, 32, 14, True),
                                                      ((10,10,10), False, 2048, 500, 8, 5, False), ((20,20,20), False, 512, 1200, 16, 6, True),
-                                                     ((6,6,6), False, 4096, 1500, 19, 6, True)]:
+                                                     ((6,6,6), False, 4096, 1500, 19, 6, True), ((10,10,10), False, 20000, 600, 64, 30, True)]:
     t0 = time.time()
-    T.spec_check(Env, oracle, size, rot, E, steps, depth, refill, native)
-    print("soak ok", size, rot, E, steps, depth, refill, native, "%.1f s" % (time.time() - t0), flush=True)
+    T.spec_check(Env, oracle, size, rot, E, steps, depth, refill, native, gen=gen)
+    print("soak ok", gen, size, rot, E, steps, depth, refill, native, "%.1f s" % (time.time() - t0), flush=True)
