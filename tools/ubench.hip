@@ -55,6 +55,11 @@ DEF_VOP2(lshl_add, "")
 DEF_VOP2(add3, "")
 #define cndmask_STEP(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(c) : );
 DEF_VOP2(cndmask, "")
+// the forms the compiler emits in the candidate loop: mask in an SGPR pair (e64), inline constants / registers as sources
+#define cndmask64c_STEP(k) asm volatile("v_cndmask_b32_e64 %0, 0, 1, s[20:21]" : "=v"(v[k]) : : "s20", "s21");
+DEF_VOP2(cndmask64c, "")
+#define cndmask64v_STEP(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(v[k]) : "v"(c) : "s20", "s21");
+DEF_VOP2(cndmask64v, "")
 #define cmp_STEP(k) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(v[k]), "v"(c) : "vcc");
 DEF_VOP2(cmp, "")
 #define cvt_ubyte_STEP(k) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(v[k]));
@@ -232,7 +237,8 @@ int main(int argc, char **argv) {
     const T tests[] = {
         {"v_add_u32", k_add_u32, 1, 1}, {"v_mul_lo_u32", k_mul_lo, 1, 1}, {"v_mul_hi_u32", k_mul_hi, 1, 1},
         {"v_mul_u32_u24", k_mul_u24, 1, 1}, {"v_mad_u32_u24", k_mad_u24, 1, 1}, {"v_lshl_add_u32", k_lshl_add, 1, 1},
-        {"v_add3_u32", k_add3, 1, 1}, {"v_cndmask_b32", k_cndmask, 1, 1}, {"v_cmp_lt_u32", k_cmp, 1, 1},
+        {"v_add3_u32", k_add3, 1, 1}, {"v_cndmask_b32", k_cndmask, 1, 1}, {"v_cndmask_b32_e64 0,1,sgpr", k_cndmask64c, 1, 1},
+        {"v_cndmask_b32_e64 v,v,sgpr", k_cndmask64v, 1, 1}, {"v_cmp_lt_u32", k_cmp, 1, 1},
         {"v_cvt_f32_ubyte1", k_cvt_ubyte, 1, 1}, {"v_ffbh_u32", k_ffbh, 1, 1}, {"v_bfe_u32", k_bfe, 1, 1},
         {"v_perm_b32", k_perm, 1, 1}, {"v_mov_b32_dpp", k_mov_dpp, 1, 1}, {"v_add_u32_dpp", k_add_dpp, 1, 1},
         {"v_readlane+v_add", k_readlane, 1, 2}, {"v_fma_f32", k_fma_f32, 1, 1}, {"v_pk_add_u16", k_pk_add_u16, 1, 1},
