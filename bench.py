@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--stream", action="store_true",
                     help="endless CUT-2 supply generated on the device (bpp_stream: no sequence is ever replayed) instead of "
                          "the finite pool of BASELINE's configs; the refill kernels run inside the timed region")
+    ap.add_argument("--stream-cache", choices=("auto", "on", "off"), default="auto",
+                    help="--stream: row cache (bpp_batch.seq_cache); auto = BppVecEnv's default")
     ap.add_argument("--stream-rng", choices=("mt19937", "counter"), default="mt19937",
                     help="--stream: mt19937 = every bin an exact random.Random(seed + id) (sequences identical to the reference "
                          "creator's under that seed); counter = the same cutting algorithm on a stateless counter-based generator "
@@ -313,7 +315,8 @@ def main():
 
     env = bpp_amd.BppVecEnv(E, size, enable_rotation=args.rotation, pool=None if args.stream else pool, device=device,
                             env_id_base=rank * E, env_id_total=world * E,
-                            stream=dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill, rng=args.stream_rng) if args.stream else None)
+                            stream=dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill, rng=args.stream_rng,
+                                        cache={"auto": None, "on": True, "off": False}[args.stream_cache]) if args.stream else None)
     stats = bpp_amd.EpisodeStats(device)
     actions = torch.empty(E, dtype=torch.int64, device=device)
     env.reset()
@@ -512,8 +515,9 @@ def main():
                                        % ("random.Random(g) per bin" if args.stream_rng == "mt19937" else
                                           "counter-based generator keyed by (seed, bin, episode), the reference's cutting algorithm",
                                           args.stream_depth, args.stream_refill,
-                                          " beside the lock-steps" if args.stream_depth >= 2 * args.stream_refill + 3
-                                          and bpp_amd._lib.get_knobs()["stream_overlap"] else "") if args.stream
+                                          (" beside the lock-steps" if args.stream_depth >= 2 * args.stream_refill + (4 if env.stream_spec["cache"] else 3)
+                                           and bpp_amd._lib.get_knobs()["stream_overlap"] else "") +
+                                          (", row cache (bpp_batch.seq_cache)" if env.stream_spec["cache"] else ", no row cache")) if args.stream
                                        else args.pool_file or "generated CUT-2 (sequences.cut2_pool, seed 0)"),
                        "sharding": "bins by global id, %d rank(s); 32-byte stats all-reduce only (%s%s)"
                                    % (world, "RCCL" if backend == "nccl" else backend,

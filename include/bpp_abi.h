@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 12
+#define BPP_ABI_VERSION 13
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -104,7 +104,23 @@ typedef struct bpp_batch {
                               binCreator.py:15-18) then comes from the ONE row it is reading anyway instead
                               of three rows scattered over a ring far larger than the caches               */
     int32_t reserved0;
+    void *seq_cache;       /* NULL, or (BPP_POOL_RING only, depth >= 5, pool_len < 8192) BPP_SEQ_CACHE_BYTES(num_envs) bytes,
+                              128-byte aligned, contents opaque, ZERO-FILLED by the caller when it is allocated and again
+                              whenever `state` or the ring are written behind the library's back (restoring a
+                              checkpoint, cloning bins): the ROW CACHE of a ring pool.  A read that misses every cache
+                              takes longer than a step workgroup lives once the step kernel's write stream saturates
+                              the memory, so one lane looking ahead into a ring far larger than the caches holds its
+                              whole workgroup back.  With a row cache the 10x10 / 20x20 step kernels keep, per bin, two
+                              128-byte lines with what its next steps look ahead to; a bin that moves to another row
+                              posts a request, copier workgroups at the front of the NEXT step launch read the ring
+                              for it, and the step after that finds the new line.  Whatever a line cannot answer is read
+                              from the ring as before: results are the same with and without the cache (every other
+                              kernel simply drops the bin's lines).  A line refers to the row after next and is built a
+                              step after it was asked for: refill at least every depth - 4 lock-steps (depth - 3
+                              without a cache).                                                                        */
 } bpp_batch;
+
+#define BPP_SEQ_CACHE_BYTES(E) ((size_t)(E) * (2 * 128 + 8 + 8))
 
 #define BPP_POOL_STATIC 0
 #define BPP_POOL_RING   1
@@ -246,6 +262,7 @@ int bpp_reset(const bpp_batch *b, int32_t mode, const bpp_step_out *out, void *s
  * bpp_batch.ep_acc (main.py:159-162); with out->host_reward / host_done set, reward and done are ALSO written into that
  * mapped host memory (acktr/envs.py:189-193 hands the loop a CPU reward tensor and a numpy done).  actions: [E] int64. */
 int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *stream);
+
 
 /* Batched drop-in for acktr.utils.get_possible_position (rotation=0, acktr/utils.py:37-62) and
  * get_rotation_mask (rotation=1, :64-94) on a [E][4*W*L] float32 observation batch. */

@@ -15,9 +15,9 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 BUILD_LIB = os.path.join(CSRC, "libbpp_hip.so")
 LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
-DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
+DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_tile_body.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 STREAM_RNG_MT19937, STREAM_RNG_COUNTER = 0, 1
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
@@ -36,7 +36,8 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("seq_cache", ctypes.c_void_p)]
 
 
 class Stream(ctypes.Structure):
@@ -49,6 +50,7 @@ class Stream(ctypes.Structure):
 
 
 POOL_STATIC, POOL_RING = 0, 1
+SEQ_CACHE_BYTES_PER_BIN = 2 * 128 + 8 + 8   # BPP_SEQ_CACHE_BYTES(E) / E
 ROLLOUT_CONTINUE = 1
 
 

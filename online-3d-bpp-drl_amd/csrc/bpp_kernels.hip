@@ -102,6 +102,8 @@ struct Params {
     int32_t ring2;         // 2 for the ring of a stream (rows start with two look-ahead entries, item i at entry 2 + i), else 0
     double binvol;
     const uint32_t *pool;  // [P][T] packed x | y<<8 | z<<16
+    unsigned char *cache;  // bpp_batch.seq_cache (see RowCache) or nullptr
+    int32_t ncopy;         // tile step kernel with a row cache: its first ncopy workgroups serve the refresh requests
     // state
     uint8_t *hmap;   // [E][A] bytes
     bpp_env_state *state;
@@ -128,6 +130,110 @@ struct Params {
     int64_t env_id_base;
 };
 
+// ---- bpp_batch.seq_cache: the row cache of a ring pool ---------------------------------------------------------------
+// A read that misses every cache takes 15-18 us under the step kernel's write stream -- longer than a step workgroup
+// lives -- so ONE lane waiting for a ring row keeps its workgroup resident past its natural end and the launch pays 6 us
+// (profiles/r4s_head_table_experiment, r4x).  With a row cache no step workgroup reads the ring: every bin has two 128-byte
+// lines (lines[e][2][32]) holding what its next steps look ahead to, a control word that says which line is current, and a
+// request slot.  The bin's deciding lanes post a request when the bin moves to another row (or its cursor nears the end of
+// the line's item window); the FIRST ncopy workgroups of the next step launch -- copier workgroups, 256 bins each, nothing
+// else to do, so their 15 us of waiting costs nothing -- read the ring rows and write the bin's OTHER line; the step after
+// that switches to it.  In between the bin lives on its old line, which also holds the first entries of the next row.
+// Anything the current line cannot answer (two rows in two steps, a line that fails its check word, a cache the caller
+// just zeroed) is read from the ring as before: the cache can only make a step faster, never change what it returns.
+//   line of (row r of episode k, first item c0), 32 words:
+//     [0..7]   entries 0..7 of the bin's NEXT row (its two look-ahead entries, items 0..5)
+//     [8],[9]  entries 0, 1 of row r (item 1 of the next row, item 0 of the row after)      [10],[11] unused
+//     [12..31] entries 2 + c0 .. 2 + c0 + 19 of row r: items c0 .. c0 + 19 (0 beyond the row)
+//   ctl[e] (uint2): x = current line | pending << 1 (0 none, 1 asked for in the previous launch, 2 written meanwhile)
+//                       | c0 of line 0 << 3 | c0 of line 1 << 16 (13 bits each)
+//                   y = (episode + 1) & 0xffff of line 0 | that of line 1 << 16 (0: no line)
+//   req[e] (uint64): 0 = nothing to do; else row | 1 << 31 | (c0 | line << 16) << 32
+// Rows: a line is built one step after it is asked for and refers to the row after next: rows up to episode + 3 must exist
+// at every step (refill at least every depth - 4 lock-steps).
+constexpr int kLineWords = 32, kLineItems = 20, kLineNext = 8;
+#ifndef BPP_CACHE_STAT   // (the host emulator of tests/emu counts hits and misses here; nothing in the product)
+#define BPP_CACHE_STAT(hit) ((void)0)
+#endif
+struct RowCache {
+    uint32_t *lines;     // [E][2][kLineWords]
+    uint2 *ctl;          // [E]
+    unsigned long long *req;   // [E]
+};
+__host__ __device__ __forceinline__ RowCache row_cache(unsigned char *base, int E) {
+    RowCache c;
+    c.lines = (uint32_t *)base;
+    c.ctl = (uint2 *)(base + (size_t)E * 2 * kLineWords * 4);
+    c.req = (unsigned long long *)(base + (size_t)E * (2 * kLineWords * 4 + 8));
+    return c;
+}
+// Kernels that do not keep the cache (resets, the runtime-geometry and generic step kernels) drop the bin's lines and any
+// request still open: the tile step kernel then reads the ring until its requests have been served again.
+__device__ __forceinline__ void row_cache_drop(const Params &p, int e) {
+    const RowCache c = row_cache(p.cache, p.E);
+    c.ctl[e] = make_uint2(0u, 0u);
+    c.req[e] = 0ull;
+}
+// A copier workgroup of the tile step kernel (its first p.ncopy workgroups) serves the open requests of kCopierBins bins,
+// a wave those of 256: it compacts them into a list in its LDS area, then eight lanes build one line (four words each), eight
+// requests per iteration, in rounds of 48 whose ring reads are ALL issued before the first line is written -- the reads miss
+// every cache, a round costs one such latency (15-18 us), and a round is all a wave ever needs in practice.  Few, fat copier
+// workgroups: each holds one of its CU's eight workgroup slots for that long.
+constexpr int kCopierBins = 4 * 256;
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ void row_cache_copier(const Params &p, int e_wave, uint32_t *list) {
+    const RowCache c = row_cache(p.cache, p.E);
+    const int lane = threadIdx.x & (kWave - 1), T = p.T;
+    int n = 0;                                      // requests of this wave's 256 bins: (row | c0 << 32 in two words, bin) triples
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = e_wave + k * kWave + lane;
+        const unsigned long long r = e < p.E ? c.req[e] : 0ull;
+        const bool valid = ((uint32_t)r >> 31) != 0u;
+        const unsigned long long m = __ballot(valid);
+        if (valid) {
+            const int at = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            list[3 * at] = (uint32_t)r & 0x7fffffffu;
+            list[3 * at + 1] = (uint32_t)(r >> 32);
+            list[3 * at + 2] = (uint32_t)e;
+        }
+        n += __popcll(m);
+    }
+    wave_sync();
+    constexpr int kRound = 6;
+    const int slot = lane >> 3, part = lane & 7;    // request within the iteration, four-word part of its line
+    for (int base = 0; base < n; base += 8 * kRound) {
+        uint32_t v[kRound][4];
+        int dst[kRound];                            // word index into c.lines, -1: nothing to do
+#pragma unroll
+        for (int i = 0; i < kRound; ++i) {
+            const int at = base + 8 * i + slot;
+            const bool act = at < n;
+            const uint32_t row = act ? list[3 * at] : 0u, hi = act ? list[3 * at + 1] : 0u, e = act ? list[3 * at + 2] : 0u;
+            const uint32_t c0 = hi & 0xffffu, buf = (hi >> 16) & 1u;
+            uint32_t rown = row + (uint32_t)p.seq_stride;
+            rown = rown >= (uint32_t)p.P ? rown - (uint32_t)p.P : rown;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = part * 4 + j;         // which ring entry goes into word w of the line (see RowCache)
+                const uint32_t ent = w < kLineNext ? (uint32_t)w : (w < 10 ? (uint32_t)(w - 8) : 2u + c0 + (uint32_t)(w - 12));
+                const bool from_ring = act && w != 10 && w != 11 && ent < (uint32_t)T;
+                v[i][j] = from_ring ? p.pool[(size_t)(w < kLineNext ? rown : row) * T + ent] : 0u;
+            }
+            dst[i] = act ? ((int)e * 2 + (int)buf) * kLineWords + part * 4 : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < kRound; ++i)
+            if (dst[i] >= 0) {
+                *(uint4 *)(c.lines + dst[i]) = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                if (part == 0) c.req[dst[i] / (2 * kLineWords)] = 0ull;     // served
+            }
+    }
+}
+struct LookAhead {
+    uint32_t ok, f1, f2;
+};
+
 __device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, int seq_n, int seq_nn, int cursor) {
     const int T = p.T, r2 = p.ring2;
     const bool ring = r2 != 0;
@@ -137,7 +243,6 @@ __device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, i
     a.f2 = (size_t)(ring ? seq : seq_nn) * T + (ring ? 1 : 0);
     return a;
 }
-
 // Episode statistics (main.py:159-162): every bin owns one row [return sum, final-ratio sum, length sum, episodes] of
 // bpp_batch.ep_acc and the lane that decides the bin adds a finished episode to it with a plain read-modify-write.
 // No atomics: a row has exactly one writer per launch, launches on a stream are ordered, so the row is the float64
@@ -172,12 +277,12 @@ struct __attribute__((aligned(16))) BinRec {
 // the bins so that cache lines shared by neighbouring waves (the small per-bin outputs, the byte heightmaps) are
 // completed inside ONE L2 instead of being written back as partial lines from several.  Bijective for any grid size;
 // affects speed only.
-__device__ __forceinline__ int xcd_block(int remap) {
-    const int b = blockIdx.x, nb = gridDim.x;
+__device__ __forceinline__ int xcd_block_of(int b, int nb, int remap) {
     if (!remap || nb < 16) return b;
     const int xcd = b & 7, q = nb >> 3, r = nb & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
+__device__ __forceinline__ int xcd_block(int remap) { return xcd_block_of((int)blockIdx.x, (int)gridDim.x, remap); }
 
 // Caller-supplied item sizes (mask-only entry points): each side is clamped into a byte so that it cannot
 // spill into its neighbour's field; a side above 255 is wider than any supported bin either way.
@@ -396,6 +501,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
                 r.flags = 2u;
             }
             p.state[e] = st;
+            if (p.cache != nullptr) row_cache_drop(p, e);
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -419,6 +525,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
             st.hmax = 0;
             p.state[e] = st;
+            if (p.cache != nullptr) row_cache_drop(p, e);
             r.item = st.item_cur;
             r.flags = 2u;
         } else if (MODE == kMaskObs) {
@@ -962,6 +1069,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 r.flags = 2u;
             }
             if (active) p.state[e] = st;
+            if (active && p.cache != nullptr) row_cache_drop(p, e);
         } else if (MODE == kResetInit || MODE == kResetAdvance) {
             bpp_env_state st;
             if (MODE == kResetInit) {
@@ -985,6 +1093,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
             st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
             st.hmax = 0;
             if (active) p.state[e] = st;
+            if (active && p.cache != nullptr) row_cache_drop(p, e);
             r.item = st.item_cur;
             r.flags = 2u;
         } else if (MODE == kMaskObs) {
@@ -2100,7 +2209,16 @@ template <int W, int L, int K, int MODE, int EPW, int NIT>
 void launch_tile_nit(const Launch &l, hipStream_t s) {
     const int nb = kTileWaves * EPW * NIT;
     const int blocks = (l.p.E + nb - 1) / nb;
-    if (l.p.rotation)
+    if (MODE == kStep && l.p.cache != nullptr) {   // row cache: copier workgroups (kCopierBins bins each) in front of the grid
+        Params q = l.p;
+        q.ncopy = (l.p.E + kCopierBins - 1) / kCopierBins;
+        if (l.p.rotation)
+            hipLaunchKernelGGL((bpp_tile_kernel_q<W, L, K, true, kStep, EPW, NIT>), dim3(blocks + q.ncopy), dim3(kWave * kTileWaves),
+                               (TileGeo<W, L, K, true, EPW, NIT>::LDS_BLOCK), s, q);
+        else
+            hipLaunchKernelGGL((bpp_tile_kernel_q<W, L, K, false, kStep, EPW, NIT>), dim3(blocks + q.ncopy), dim3(kWave * kTileWaves),
+                               (TileGeo<W, L, K, false, EPW, NIT>::LDS_BLOCK), s, q);
+    } else if (l.p.rotation)
         hipLaunchKernelGGL((bpp_tile_kernel<W, L, K, true, MODE, EPW, NIT>), dim3(blocks), dim3(kWave * kTileWaves),
                            (TileGeo<W, L, K, true, EPW, NIT>::LDS_BLOCK), s, l.p);
     else
@@ -2167,10 +2285,17 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
         p.seq_stride = b->num_envs % b->pool_size;
         p.ring2 = 2;
         p.base_mod = 0;
+        if (b->seq_cache != nullptr) {
+            if ((uintptr_t)b->seq_cache & 127u) return fail(BPP_E_BADARG, "bpp_batch: seq_cache must be 128-byte aligned");
+            if (b->pool_size / b->num_envs < 5) return fail(BPP_E_BADARG, "bpp_batch: seq_cache needs a ring of depth >= 5");
+            if (b->pool_len > 0x1fff) return fail(BPP_E_BADARG, "bpp_batch: seq_cache needs pool_len < 8192");
+            p.cache = (unsigned char *)b->seq_cache;
+        }
     } else if (b->pool_mode == BPP_POOL_STATIC) {
         p.seq_stride = (int32_t)(b->env_id_total % b->pool_size);
         p.ring2 = 0;
         p.base_mod = (int32_t)(b->env_id_base % b->pool_size);
+        if (b->seq_cache != nullptr) return fail(BPP_E_BADARG, "bpp_batch: seq_cache goes with BPP_POOL_RING");
     } else {
         return fail(BPP_E_BADARG, "bpp_batch: unknown pool_mode");
     }
@@ -2695,17 +2820,18 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) { return stream_refill(
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
                                int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
     if (!b || !s) return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: NULL pointer");
-    if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - 3)
-        return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");
+    const int behind = b->seq_cache ? 4 : 3;   // rows a step launch may touch from the current one on (a cache line refers to the row after next)
+    if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - behind)
+        return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3 (- 4 with seq_cache)");
     int rc = 0;
-    // With depth >= 2 R + 3 rows per bin the refill that follows a chunk of R lock-steps may run BESIDE the next chunk
+    // (3 below stands for `behind`.)  With depth >= 2 R + 3 rows per bin the refill that follows a chunk of R lock-steps may run BESIDE the next chunk
     // (it only rewrites rows of finished episodes): it goes to a side stream, and a chunk starts once the refill issued two
     // chunks earlier is complete.  Margin m = rows a bin has from its current episode on when a refill scans it (the
     // previous refill is complete by then: same stream).  A bin advances by at most R episodes per chunk and a step reads
     // two rows ahead, so it needs m >= R + 3 to get through the chunk that runs beside the refill and m + need >= 2 R + 3
     // to get through the one after (this refill complete, the next one running).  The scan guarantees the second
     // (need >= 2 R + 3 - m, `urgent`), which also gives the first for the next scan: m' >= m + need - R >= R + 3.
-    SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + 3) ? side_stream() : nullptr;
+    SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + behind) ? side_stream() : nullptr;
     hipStream_t main = (hipStream_t)stream;
     std::unique_lock<std::mutex> hold;
     if (side) hold = std::unique_lock<std::mutex>(side->in_use);
@@ -2724,7 +2850,7 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
         // beside the lock-steps a short refill matters more than a full ring: a bin gets about twice what the average
         // bin uses in refill_every lock-steps (one sequence per ~9), more only if it would otherwise run out before the
         // refill after the next one is complete
-        rc = stream_refill(s, side->stream, refill_every < 7 ? 2 : (refill_every + 5) / 6, 2 * refill_every + 3);
+        rc = stream_refill(s, side->stream, refill_every < 7 ? 2 : (refill_every + 5) / 6, 2 * refill_every + behind);
         (void)hipEventRecord(side->refilled[chunk & 1], side->stream);
     }
     if (side) {     // everything enqueued on `stream` after this call sees the refilled ring

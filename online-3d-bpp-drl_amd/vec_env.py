@@ -298,13 +298,22 @@ class BppVecEnv(object):
             else:
                 lo, hi = (int(v) for v in stream.get("bound", (2, 5)))
                 depth = int(stream.get("depth", 8))
-                if depth < 4:
-                    raise ValueError("stream depth must be >= 4")
+                # bpp_batch.seq_cache: the row cache (include/bpp_abi.h) -- no step workgroup waits for a read of the ring;
+                # its lines refer to the row after next, which costs one row of look-ahead.  Default: wherever the refill
+                # schedule leaves that row
+                if stream.get("cache") is not None:
+                    cache = bool(stream["cache"])
+                else:
+                    cache = depth >= 5 and depth - int(stream.get("refill_every", 1)) >= 4 and \
+                        int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3)) < 8192
+                behind = 4 if cache else 3
+                if depth < behind + 1:
+                    raise ValueError("stream depth must be >= %d" % (behind + 1))
                 # entries per ring row: two look-ahead entries (include/bpp_abi.h), the longest possible sequence, the terminator
                 pool_len = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3))
-                self.refill_every = int(stream.get("refill_every", depth - 3))
-                if not 1 <= self.refill_every <= depth - 3:
-                    raise ValueError("refill_every must be in 1 .. depth - 3")
+                self.refill_every = int(stream.get("refill_every", depth - behind))
+                if not 1 <= self.refill_every <= depth - behind:
+                    raise ValueError("refill_every must be in 1 .. depth - %d" % behind)
                 self.pool = torch.zeros((depth * self.E, pool_len, 4), dtype=torch.uint8, device=dev)   # the ring
                 sizes = (ctypes.c_int64 * 2)()      # the two opaque buffers of a bpp_stream: generator records, scratch
                 rng = {"mt19937": _lib.STREAM_RNG_MT19937, "counter": _lib.STREAM_RNG_COUNTER}[stream.get("rng", "mt19937")]
@@ -314,9 +323,10 @@ class BppVecEnv(object):
                 self._work = torch.zeros(((int(sizes[1]) + 15) // 16, 4), dtype=torch.int32, device=dev)
                 self.gen_next = torch.zeros((self.E,), dtype=torch.int32, device=dev)
                 self.stream_overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
+                self._seq_cache = torch.zeros((self.E * _lib.SEQ_CACHE_BYTES_PER_BIN,), dtype=torch.uint8, device=dev) if cache else None
                 pool_rows, pool_mode = depth * self.E, _lib.POOL_RING
                 self.stream_spec = dict(bound=(lo, hi), seed=int(stream.get("seed", 0)), depth=depth, pool_len=pool_len,
-                                        refill_every=self.refill_every, rng=stream.get("rng", "mt19937"))
+                                        refill_every=self.refill_every, rng=stream.get("rng", "mt19937"), cache=cache)
             self.hmap = torch.zeros((self.E, self.A), dtype=torch.uint8, device=dev)  # Space.plain as bytes
             self.state = torch.zeros((self.E, 12), dtype=torch.int32, device=dev)  # bpp_env_state[E], 48 B each
             # episode statistics kept inside the step kernel, one row per bin: [return sum, final-ratio sum, length
@@ -325,7 +335,8 @@ class BppVecEnv(object):
         self._batch = _lib.Batch(self.E, self.W, self.L, self.H, int(self.can_rotate), self.mask_rule,
                                  pool_rows, pool_len, self.env_id_base, self.env_id_total,
                                  self.pool.data_ptr(), self.hmap.data_ptr(), self.state.data_ptr(),
-                                 self.ep_acc.data_ptr(), pool_mode, 0)
+                                 self.ep_acc.data_ptr(), pool_mode, 0,
+                                 self._seq_cache.data_ptr() if self.stream_spec is not None and self._seq_cache is not None else None)
         self._batch_ref = ctypes.byref(self._batch)
         self._stream = None
         self._since_refill = 0
@@ -510,6 +521,12 @@ class BppVecEnv(object):
         self._on_device()
         _lib.check(self.lib.bpp_stream_refill(ctypes.byref(self._stream), self._stream_ptr()))
         self._since_refill = 0
+
+    def _reset_seq_cache(self):
+        """`state` or the ring were written behind the library's back: zero the row cache (the kernels then read the ring
+        until their refresh requests have been served again)."""
+        if self._stream is not None and self._seq_cache is not None:
+            self._seq_cache.zero_()
 
     def _stepped(self, n=1):
         if self._stream is not None:
@@ -773,6 +790,7 @@ class BppVecEnv(object):
         if self._stream is not None:
             copy_bin_records(self.hmap, self.state, src, dst, ring=self.pool, mt=self._mt, gen_next=self.gen_next,
                              depth=self.stream_spec["depth"])
+            self._reset_seq_cache()
         else:
             copy_bin_records(self.hmap, self.state, src, dst)
 
@@ -849,6 +867,9 @@ class BppVecEnv(object):
             self._mt.copy_(sd["stream_mt"])
             self.gen_next.copy_(sd["stream_gen_next"])
             self._since_refill = int(sd["stream_since_refill"])
+            self._reset_seq_cache()
+            if self._since_refill >= self.refill_every:   # (written by an env with a longer refill period)
+                self.refill()
         if "obs" in sd:
             bufs, _ = self._buffers()
             if self._res is None or self.fresh_outputs:

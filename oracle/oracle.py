@@ -27,7 +27,8 @@ class Batch(ctypes.Structure):
                 ("rotation", ctypes.c_int32), ("mask_rule", ctypes.c_int32), ("pool_size", ctypes.c_int32),
                 ("pool_len", ctypes.c_int32), ("env_id_base", ctypes.c_int64), ("env_id_total", ctypes.c_int64),
                 ("seq_pool", ctypes.c_void_p), ("hmap", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("ep_acc", ctypes.c_void_p), ("pool_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("seq_cache", ctypes.c_void_p)]
 
 
 class Stream(ctypes.Structure):
@@ -130,6 +131,13 @@ def _aligned_zeros(nbytes, align=64):
     return raw[off:off + nbytes]
 
 
+def _stream_cache(stream, depth):
+    """Same default as BppVecEnv: a row cache wherever the refill schedule leaves the extra row of look-ahead."""
+    if stream.get("cache") is not None:
+        return bool(stream["cache"])
+    return depth >= 5 and depth - int(stream.get("refill_every", 1)) >= 4
+
+
 class OracleEnv(object):
     """E bins stepped in lock-step on the host by the C restatement."""
 
@@ -143,6 +151,9 @@ class OracleEnv(object):
             D = int(stream.get("depth", 8))
             T = int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3))   # 2 look-ahead entries + items + terminator
             pool = np.zeros((D * int(num_envs), T, 4), np.uint8)
+            # bpp_batch.seq_cache (include/bpp_abi.h): the row cache of the device library; the restatement ignores it, the
+            # emulated product (tests/emu loads this class over its own library) runs its cache-keeping kernels with it
+            self.seq_cache = _aligned_zeros(int(num_envs) * (2 * 128 + 8 + 8), 128) if _stream_cache(stream, D) else None
         self.pool = np.ascontiguousarray(pool, dtype=np.uint8)
         assert self.pool.ndim == 3 and self.pool.shape[2] == 4
         self.A = self.W * self.L
@@ -160,7 +171,8 @@ class OracleEnv(object):
                         self.pool.shape[1], int(env_id_base),
                         int(env_id_total if env_id_total is not None else env_id_base + self.E),
                         _p(self.pool).value, _p(self.hmap).value, _p(self.state).value, _p(self.ep_acc).value,
-                        1 if stream is not None else 0, 0)
+                        1 if stream is not None else 0, 0,
+                        _p(self.seq_cache).value if stream is not None and self.seq_cache is not None else None)
         if stream is not None:
             E = self.E
             self.gen_next = np.zeros(E, np.int32)
@@ -174,13 +186,17 @@ class OracleEnv(object):
             self._mt = _aligned_zeros(int(sizes[0]) * 4)
             self._work = _aligned_zeros(int(sizes[1]))
             self.stream.mt, self.stream.work = _p(self._mt).value, _p(self._work).value
-            self.refill_every = int(stream.get("refill_every", max(1, D - 3)))
+            self.refill_every = int(stream.get("refill_every", max(1, D - (4 if self.seq_cache is not None else 3))))
             self._since_refill = 0
             _check(lib().bpp_stream_init(ctypes.byref(self.stream), None))
             self.refill()
         self._o = StepOut(*[_p(self.out[k]).value for k in ("obs", "mask", "reward", "done", "counter", "ratio",
                                                               "ep_ret", "ep_len")])
         self._first = True
+
+    def reset_seq_cache(self):
+        """`state` or the ring were written behind the library's back: zero the row cache (include/bpp_abi.h)."""
+        self.seq_cache[:] = 0
 
     def refill(self):
         _check(lib().bpp_stream_refill(ctypes.byref(self.stream), None))

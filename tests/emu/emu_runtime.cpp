@@ -225,3 +225,6 @@ void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()> &body
 }  // namespace emu
 
 #include "../../online-3d-bpp-drl_amd/csrc/bpp_kernels.hip"
+
+long long g_emu_cache_stat[2] = {0, 0};
+extern "C" long long *emu_cache_stat() { return g_emu_cache_stat; }

@@ -38,12 +38,12 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_limits(lib):
-    assert lib.bpp_abi_version() == 12
+    assert lib.bpp_abi_version() == 13
     assert _lib.limits() == (1024, 255)
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.Batch) == 8 * 4 + 2 * 8 + 4 * 8 + 8
+    assert ctypes.sizeof(_lib.Batch) == 8 * 4 + 2 * 8 + 4 * 8 + 8 + 8 and _lib.Batch.seq_cache.offset == 88
     assert _lib.Batch.env_id_base.offset == 32 and _lib.Batch.seq_pool.offset == 48
     assert ctypes.sizeof(_lib.StepOut) == 64 + 24 + 16
     from oracle import oracle as orc
@@ -63,6 +63,11 @@ def test_argument_validation_happens_before_any_device_work(lib):
     assert lib.bpp_mask_from_hmap(16, 16, 16, 0, 10, 10, 10, 0, 0, None) == -1  # E <= 0
     assert lib.bpp_sample_feasible(None, None, 1, 1, 0, 0, 0, None) == -1
     assert lib.bpp_reset(ctypes.byref(b2), 5, ctypes.byref(o), None) == -1      # bad mode
+    o2 = _lib.StepOut(16)
+    b3 = _lib.Batch(16, 10, 10, 10, 0, 0, 4, 8, 0, 16, 16, 16, 16, None, _lib.POOL_STATIC, 0, 128)
+    assert lib.bpp_reset(ctypes.byref(b3), 0, ctypes.byref(o2), None) == -1 and b"seq_cache" in lib.bpp_last_error()   # a row cache needs a ring
+    b4 = _lib.Batch(16, 10, 10, 10, 0, 0, 64, 8, 0, 16, 16, 16, 16, None, _lib.POOL_RING, 0, 128)
+    assert lib.bpp_reset(ctypes.byref(b4), 0, ctypes.byref(o2), None) == -1 and b"depth >= 5" in lib.bpp_last_error()
 
 
 def test_no_silent_cpu_fallback():

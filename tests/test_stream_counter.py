@@ -103,6 +103,7 @@ def test_emulated_counter_clone_continues_the_sources_stream(emu):
     ring, mt, gn = torch.from_numpy(env.pool), torch.from_numpy(env._mt.view(np.int32).reshape(E, -1)), torch.from_numpy(env.gen_next)
     assert mt.shape[1] == 4
     copy_bin_records(hm, st, torch.tensor([0]), torch.tensor([1]), ring=ring, mt=mt, gen_next=gn, depth=depth)
+    env.reset_seq_cache()                          # (BppVecEnv.copy_bins does the same)
     for t in range(2 * depth):                      # the source burns through > depth episodes; everybody else waits
         a = np.full(E, NOOP, np.int64)
         a[0] = -1

@@ -43,14 +43,22 @@ class EmuStreamEnv(object):
                                                                   # a bin that holds two or three items: episodes shorter than
                                                                   # the refill interval, bins fall behind and become urgent
                                                                   ((6, 6, 6), False, 70, 60, 19, 6, True),
-                                                                  ((6, 6, 6), True, 33, 45, 24, 8, True)])
+                                                                  ((6, 6, 6), True, 33, 45, 24, 8, True),
+                                                                  # tightest schedules with a row cache (depth - refill == 4)
+                                                                  ((10, 10, 10), False, 70, 60, 8, 4, False),
+                                                                  ((10, 10, 10), True, 33, 40, 5, 1, False),
+                                                                  ((20, 20, 20), False, 5, 30, 6, 2, True),
+                                                                  ((6, 6, 6), False, 70, 60, 10, 6, True),
+                                                                  # W*L % 4 != 0: the generic cell-scan kernel drops the cache lines
+                                                                  ((7, 9, 8), False, 20, 40, 9, 3, False)])
 def test_emulated_stream_supply_matches_oracle_and_python_random(emu, oracle, size, rot, E, steps, depth, refill, native):
     spec_check(lambda sz, r, n, base, spec: EmuStreamEnv(emu, sz, r, n, base, spec), oracle, size, rot, E, steps, depth, refill, native)
 
 
 def spec_check(make_env, oracle, size, rot, E, steps, depth, refill, native, gen="mt19937"):
     base, seed = 1000, 77
-    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill, rng=gen)
+    # row cache (bpp_batch.seq_cache) wherever the schedule leaves the row of look-ahead it costs
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill, rng=gen, cache=depth - refill >= 4)
     env = make_env(size, rot, E, base, spec)
     ref = oracle.OracleEnv(None, size, rot, E, env_id_base=base, env_id_total=base + E + 3, stream=spec)
     obs, mask = env.reset()
@@ -101,7 +109,8 @@ def knob_check(front, oracle, set_knobs, size, E, depth, steps, pattern, refill=
     """Fast pipeline (scan / cut / sort) and the one-lane-per-bin kernel are interchangeable refill by refill: `pattern(t)`
     chooses which one serves lock-step t.  Everything a step returns and, at the end, the whole ring must equal the
     oracle's (its generator is the plain-C one of include/bpp_gen.inl)."""
-    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill or max(1, depth - 3), rng=gen)
+    refill = refill or max(1, depth - 3)
+    spec = dict(bound=(2, 5), seed=seed, depth=depth, refill_every=refill, rng=gen, cache=depth - refill >= 4)
     set_knobs(stream_legacy=pattern(0))
     try:
         env = front(size, E, base, spec)
@@ -177,7 +186,13 @@ def test_emulated_refill_after_many_episodes_without_refill(emu, oracle):
                                                                   ((10, 10, 10), False, 65536, 60, 8, 5, True),
                                                                   ((20, 20, 20), False, 300, 400, 6, 3, True),
                                                                   ((6, 6, 6), False, 5000, 200, 19, 6, True),
-                                                                  ((10, 10, 10), False, 20000, 150, 32, 14, True)])
+                                                                  ((10, 10, 10), False, 20000, 150, 32, 14, True),
+                                                                  # depth - refill >= 4: with the row cache (copier workgroups,
+                                                                  # E not a multiple of their 1024 bins, forced failures)
+                                                                  ((10, 10, 10), False, 4099, 120, 9, 4, False),
+                                                                  ((10, 10, 10), True, 2000, 300, 12, 5, True),
+                                                                  ((10, 10, 10), False, 65536, 60, 16, 6, True),
+                                                                  ((20, 20, 20), False, 300, 400, 10, 3, True)])
 def test_gpu_stream_supply_matches_oracle_and_python_random(oracle, size, rot, E, steps, depth, refill, native):
     import torch
     import bpp_amd
@@ -341,6 +356,8 @@ def test_emulated_streaming_clone_continues_the_sources_item_stream(emu):
     mt = torch.from_numpy(env._mt.view(np.int32).reshape(E, -1))
     gn = torch.from_numpy(env.gen_next)
     copy_bin_records(hm, st, torch.tensor([0]), torch.tensor([1]), ring=ring, mt=mt, gen_next=gn, depth=depth)
+    assert env.seq_cache is not None
+    env.reset_seq_cache()          # state and ring were written behind the library's back (BppVecEnv.copy_bins does the same)
     assert int(env.state["seq"][1]) == int(env.state["seq"][0]) + 1        # same ring row index, the copy's own column
     # bin 0 fails 2 * depth times in a row (refill after every lock-step rewrites its column); every other bin waits
     for t in range(2 * depth):
@@ -434,3 +451,106 @@ def test_gpu_stream_checkpoints_are_validated_on_load():
     with pytest.raises(ValueError, match="stream_spec"):
         bpp_amd.BppVecEnv(64, size, stream=spec, env_id_base=64, env_id_total=128).load_state_dict(sd)
     bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(sd)      # the matching env loads
+
+
+def test_emulated_row_cache_answers_the_look_aheads(emu, oracle):
+    """bpp_batch.seq_cache is not just harmless, it works: under the benchmark's policy (fused uniform-feasible draw) all
+    but the first look-aheads of a rollout are answered by the bins' cache lines -- the ring is read only while the first
+    requests are on their way -- and the results still equal the oracle's, which knows nothing of the cache.  A zeroed
+    cache (what a checkpoint restore leaves) recovers the same way."""
+    import ctypes
+    size, E, base = (10, 10, 10), 96, 500
+    spec = dict(bound=(2, 5), seed=3, depth=12, refill_every=4, rng="counter", cache=True)
+    env = emu.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E, stream=spec)
+    ref = oracle.OracleEnv(None, size, False, E, env_id_base=base, env_id_total=base + E, stream=dict(spec, cache=False))
+    env.reset(), ref.reset()
+    stat_fn = emu.lib().emu_cache_stat
+    stat_fn.restype = ctypes.POINTER(ctypes.c_longlong)
+    stat = stat_fn()
+
+    def run(step0, n):
+        stat[0] = stat[1] = 0
+        r, ra = emu.rollout_uniform(env, 9, step0, n)
+        o, oa = oracle.rollout_uniform(ref, 9, step0, n)
+        np.testing.assert_array_equal(ra, oa)
+        for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=k)
+        return int(stat[0]), int(stat[1])
+
+    miss, hit = run(0, 40)
+    assert miss + hit == 40 * E
+    assert miss <= 2 * E + E // 8, (miss, hit)          # two lock-steps until the first lines arrive, then next to nothing
+    miss, hit = run(40, 40)
+    assert miss + hit == 40 * E and miss <= E // 8, (miss, hit)
+    assert int(ref.state["episode"].min()) >= 3        # every bin moved through several rows meanwhile
+    env.reset_seq_cache()                              # restore / clone: the caller zeroes the cache
+    miss, hit = run(80, 30)
+    assert 2 * E <= miss <= 2 * E + E // 8 and hit >= 27 * E - E // 8, (miss, hit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,rot,E,gen", [((10, 10, 10), False, 5000, "counter"), ((10, 10, 10), True, 3000, "mt19937"),
+                                            ((20, 20, 20), False, 1500, "counter")])
+def test_gpu_row_cache_on_equals_off_through_kernel_switches_clones_and_restores(size, rot, E, gen):
+    """bpp_batch.seq_cache changes nothing but speed: two streaming envs, one with and one without the row cache, stepped
+    with the same actions -- one bin in six fails on purpose, so bins race through their rows (two rows in two steps: the
+    case a line cannot answer), some bins are left alone (NOOP) -- while the launch shape changes under them (the generic
+    and runtime-geometry kernels drop the cache lines, the tile kernel has to recover), bins are cloned and a checkpoint is
+    restored (the host zeroes the cache).  Every output of every step and the final records must be equal."""
+    import torch
+    import bpp_amd
+    from bpp_amd import _lib
+    spec = dict(bound=(2, 5), seed=13, depth=12, refill_every=4, rng=gen)
+    on = bpp_amd.BppVecEnv(E, size, enable_rotation=rot, stream=dict(spec, cache=True), env_id_base=7, env_id_total=7 + E)
+    off = bpp_amd.BppVecEnv(E, size, enable_rotation=rot, stream=dict(spec, cache=False), env_id_base=7, env_id_total=7 + E)
+    assert on._seq_cache is not None and off._seq_cache is None
+    np.testing.assert_array_equal(on.reset().cpu().numpy(), off.reset().cpu().numpy())
+    rng = np.random.RandomState(5)
+    old = _lib.get_knobs()
+    try:
+        for t in range(150):
+            _lib.set_knobs(force_generic=int(t % 23 in (7, 8)), legacy_fast=int(t % 31 == 12), tile_groups=(0, 2, 4)[(t // 40) % 3])
+            a = on.sample_feasible(3, t).cpu().numpy()
+            a[rng.rand(E) < 1.0 / 6] = -1
+            a[rng.rand(E) < 0.05] = bpp_amd.BppVecEnv.NOOP
+            r1, r0 = on.step_tensors(a), off.step_tensors(a)
+            for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(getattr(r1, k).cpu().numpy(), getattr(r0, k).cpu().numpy(), err_msg="%s t=%d" % (k, t))
+            if t == 60:
+                src, dst = np.arange(0, 40), np.arange(100, 140)
+                on.copy_bins(src, dst), off.copy_bins(src, dst)
+            if t == 90:
+                on.load_state_dict(on.state_dict())
+    finally:
+        _lib.set_knobs(**old)
+    np.testing.assert_array_equal(on.state.cpu().numpy(), off.state.cpu().numpy())
+    np.testing.assert_array_equal(on.pool.cpu().numpy(), off.pool.cpu().numpy())
+    assert int(on.state[:, 1].max()) >= 8        # bpp_env_state.episode: bins went through many rows
+
+
+@pytest.mark.parametrize("size,rot,E,gen", [((10, 10, 10), False, 70, "counter"), ((20, 20, 20), False, 9, "mt19937")])
+def test_emulated_row_cache_survives_kernel_switches(emu, oracle, size, rot, E, gen):
+    """The CPU half of test_gpu_row_cache_on_equals_off_...: the emulated product with a row cache against the oracle
+    while the launch shape changes (kernels that drop the cache lines in between), with forced failures and NOOPs."""
+    base = 40
+    spec = dict(bound=(2, 5), seed=13, depth=12, refill_every=4, rng=gen, cache=True)
+    env = emu.OracleEnv(None, size, rot, E, env_id_base=base, env_id_total=base + E, stream=spec)
+    ref = oracle.OracleEnv(None, size, rot, E, env_id_base=base, env_id_total=base + E, stream=dict(spec, cache=False))
+    (obs, mask), (robs, rmask) = env.reset(), ref.reset()
+    np.testing.assert_array_equal(obs, robs)
+    rng = np.random.RandomState(5)
+    try:
+        for t in range(70):
+            emu.set_knobs(force_generic=int(t % 23 in (7, 8)), legacy_fast=int(t % 31 == 12), tile_groups=(0, 2, 4)[(t // 20) % 3])
+            a = oracle.sample_feasible(rmask, 3, t, env_id_base=base)
+            a[rng.rand(E) < 1.0 / 6] = -1
+            a[rng.rand(E) < 0.05] = -2 ** 63
+            r, o = env.step(a), ref.step(a)
+            for k in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg="%s t=%d" % (k, t))
+            rmask = o["mask"]
+    finally:
+        emu.set_knobs()
+    for f in ("cursor", "episode", "seq", "item_cur", "item_next", "item_reset"):
+        np.testing.assert_array_equal(env.state[f], ref.state[f], err_msg=f)
+    assert int(ref.state["episode"].max()) >= 6
