@@ -176,7 +176,7 @@ __device__ __forceinline__ void row_cache_drop(const Params &p, int e) {
 }
 // A copier workgroup of the tile step kernel (its first p.ncopy workgroups) serves the open requests of kCopierBins bins,
 // a wave those of 256: it compacts them into a list in its LDS area, then eight lanes build one line (four words each), eight
-// requests per iteration, in rounds of 48 whose ring reads are ALL issued before the first line is written -- the reads miss
+// requests per iteration, in rounds of 64 whose ring reads are ALL issued before the first line is written -- the reads miss
 // every cache, a round costs one such latency (15-18 us), and a round is all a wave ever needs in practice.  Few, fat copier
 // workgroups: each holds one of its CU's eight workgroup slots for that long.
 constexpr int kCopierBins = 4 * 256;
@@ -200,17 +200,15 @@ __device__ __forceinline__ void row_cache_copier(const Params &p, int e_wave, ui
         n += __popcll(m);
     }
     wave_sync();
-    constexpr int kRound = 6;
+    constexpr int kRound = 8;
     const int slot = lane >> 3, part = lane & 7;    // request within the iteration, four-word part of its line
     for (int base = 0; base < n; base += 8 * kRound) {
         uint32_t v[kRound][4];
-        int dst[kRound];                            // word index into c.lines, -1: nothing to do
 #pragma unroll
         for (int i = 0; i < kRound; ++i) {
             const int at = base + 8 * i + slot;
             const bool act = at < n;
-            const uint32_t row = act ? list[3 * at] : 0u, hi = act ? list[3 * at + 1] : 0u, e = act ? list[3 * at + 2] : 0u;
-            const uint32_t c0 = hi & 0xffffu, buf = (hi >> 16) & 1u;
+            const uint32_t row = act ? list[3 * at] : 0u, c0 = act ? list[3 * at + 1] & 0xffffu : 0u;
             uint32_t rown = row + (uint32_t)p.seq_stride;
             rown = rown >= (uint32_t)p.P ? rown - (uint32_t)p.P : rown;
 #pragma unroll
@@ -220,14 +218,16 @@ __device__ __forceinline__ void row_cache_copier(const Params &p, int e_wave, ui
                 const bool from_ring = act && w != 10 && w != 11 && ent < (uint32_t)T;
                 v[i][j] = from_ring ? p.pool[(size_t)(w < kLineNext ? rown : row) * T + ent] : 0u;
             }
-            dst[i] = act ? ((int)e * 2 + (int)buf) * kLineWords + part * 4 : -1;
         }
 #pragma unroll
-        for (int i = 0; i < kRound; ++i)
-            if (dst[i] >= 0) {
-                *(uint4 *)(c.lines + dst[i]) = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);
-                if (part == 0) c.req[dst[i] / (2 * kLineWords)] = 0ull;     // served
+        for (int i = 0; i < kRound; ++i) {
+            const int at = base + 8 * i + slot;     // (the list again: cheaper than carrying the addresses past the loads)
+            if (at < n) {
+                const uint32_t buf = (list[3 * at + 1] >> 16) & 1u, e = list[3 * at + 2];
+                *(uint4 *)(c.lines + ((size_t)e * 2 + buf) * kLineWords + part * 4) = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                if (part == 0) c.req[e] = 0ull;     // served
             }
+        }
     }
 }
 struct LookAhead {
