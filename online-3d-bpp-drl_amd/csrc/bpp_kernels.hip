@@ -136,11 +136,11 @@ struct Params {
 // (profiles/r4s_head_table_experiment, r4x).  With a row cache no step workgroup reads the ring: every bin has two 128-byte
 // lines (lines[e][2][32]) holding what its next steps look ahead to, a control word that says which line is current, and a
 // request slot.  The bin's deciding lanes post a request when the bin moves to another row (or its cursor nears the end of
-// the line's item window); the FIRST ncopy workgroups of the next step launch -- copier workgroups, 256 bins each, nothing
-// else to do, so their 15 us of waiting costs nothing -- read the ring rows and write the bin's OTHER line; the step after
+// the line's item window); the FIRST ncopy workgroups of the next step launch -- copier workgroups, 1 024 bins each, nothing
+// else to do, so their 15 us of waiting holds up nobody -- read the ring rows and write the bin's OTHER line; the step after
 // that switches to it.  In between the bin lives on its old line, which also holds the first entries of the next row.
-// Anything the current line cannot answer (two rows in two steps, a line that fails its check word, a cache the caller
-// just zeroed) is read from the ring as before: the cache can only make a step faster, never change what it returns.
+// Anything the current line cannot answer (two rows in two steps, a cache the caller just zeroed, the one episode in
+// 65 536 whose tag would be 0) is read from the ring as before: the cache can only make a step faster, never change what it returns.
 //   line of (row r of episode k, first item c0), 32 words:
 //     [0..7]   entries 0..7 of the bin's NEXT row (its two look-ahead entries, items 0..5)
 //     [8],[9]  entries 0, 1 of row r (item 1 of the next row, item 0 of the row after)      [10],[11] unused
@@ -230,10 +230,6 @@ __device__ __forceinline__ void row_cache_copier(const Params &p, int e_wave, ui
         }
     }
 }
-struct LookAhead {
-    uint32_t ok, f1, f2;
-};
-
 __device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, int seq_n, int seq_nn, int cursor) {
     const int T = p.T, r2 = p.ring2;
     const bool ring = r2 != 0;
