@@ -168,6 +168,31 @@ __global__ __launch_bounds__(256) void k_write4(uint32_t *out, size_t n, uint32_
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c + (uint32_t)i;
 }
+__global__ __launch_bounds__(256) void k_write8(uint2 *out, size_t n, uint32_t c) {  // 8 B per lane stores
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = make_uint2(c, (uint32_t)i);
+}
+__global__ __launch_bounds__(256) void k_write16_nt(uint4 *out, size_t n, uint32_t c) {  // 16 B per lane, nontemporal
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t *q = (uint32_t *)(out + i);
+        __builtin_nontemporal_store(c, q);
+        __builtin_nontemporal_store(c + 1, q + 1);
+        __builtin_nontemporal_store(c + 2, q + 2);
+        __builtin_nontemporal_store((uint32_t)i, q + 3);
+    }
+}
+// the same bytes, every workgroup its own contiguous chunk (the step kernel's pattern: a workgroup writes its bins' rows)
+__global__ __launch_bounds__(256) void k_write16_chunk(uint4 *out, size_t n, uint32_t c) {
+    const size_t per = n / gridDim.x;
+    uint4 *o = out + (size_t)blockIdx.x * per;
+    for (size_t i = threadIdx.x; i < per; i += blockDim.x) o[i] = make_uint4(c, c + 1, c + 2, (uint32_t)i);
+}
+__global__ __launch_bounds__(256) void k_write4_chunk(uint32_t *out, size_t n, uint32_t c) {
+    const size_t per = n / gridDim.x;
+    uint32_t *o = out + (size_t)blockIdx.x * per;
+    for (size_t i = threadIdx.x; i < per; i += blockDim.x) o[i] = c + (uint32_t)i;
+}
 __global__ __launch_bounds__(256) void k_copy16(const uint4 *in, uint4 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
@@ -225,6 +250,11 @@ int main(int argc, char **argv) {
         run("read16", [&] { hipLaunchKernelGGL(k_read16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, dout, bytes / 16); });
         run("write4", [&] { hipLaunchKernelGGL(k_write4, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
         run("write16", [&] { hipLaunchKernelGGL(k_write16, dim3(grid), dim3(256), 0, 0, b, bytes / 16, 7u); });
+        run("write8", [&] { hipLaunchKernelGGL(k_write8, dim3(grid), dim3(256), 0, 0, (uint2 *)b, bytes / 8, 7u); });
+        run("write16_nontemporal", [&] { hipLaunchKernelGGL(k_write16_nt, dim3(grid), dim3(256), 0, 0, b, bytes / 16, 7u); });
+        run("write16_chunk_per_workgroup", [&] { hipLaunchKernelGGL(k_write16_chunk, dim3(grid), dim3(256), 0, 0, b, bytes / 16, 7u); });
+        run("write4_chunk_per_workgroup", [&] { hipLaunchKernelGGL(k_write4_chunk, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
+        run("write16_chunk_4096_workgroups", [&] { hipLaunchKernelGGL(k_write16_chunk, dim3(4096), dim3(256), 0, 0, b, bytes / 16, 7u); });
         run("copy16_half", [&] { hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, b, bytes / 32); });
         return 0;
     }
