@@ -14,6 +14,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
     constexpr int NPASS = T::NPASS, NBW = T::NBW;
     constexpr bool BAL_REGS = NPASS <= 2;   // ballots stay in scalar registers (fully unrolled passes)
     constexpr bool kAccLate = EPW > 1;
+    constexpr bool kNtOut = A >= 400 && MODE != kResetInit && MODE != kResetAdvance;   // nontemporal output stores (store_out4_nt in bpp_tile_kernel.inl; a reset's are slower with them: 40 -> 52 us)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -468,11 +469,15 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
                         if (pl == 0) {
                             const uint32_t v = hm32[el * A4 + q];
                             gh[G * k] = v;
-                            go[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                    (float)(v >> 24));
+                            if constexpr (kNtOut)
+                                store_out4_nt(go + G * k, (float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+                            else
+                                go[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
+                                                        (float)(v >> 24));
                         } else {
                             const float f = pl == 1 ? fx : (pl == 2 ? fy : fz);
-                            go[G * k] = make_float4(f, f, f, f);
+                            if constexpr (kNtOut) store_out4_nt(go + G * k, f, f, f, f);
+                            else go[G * k] = make_float4(f, f, f, f);
                         }
                     }
                 }
@@ -795,7 +800,10 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
             for (int k = 0; k < KM; ++k)
                 if (sl + G * k < M4) {
                     const uint32_t v = anyf ? mk32[el * M4 + sl + G * k] : 0x01010101u;
-                    gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+                    if constexpr (kNtOut)
+                        store_out4_nt(gm + G * k, (float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+                    else
+                        gm[G * k] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
                 }
         }
         if (it == NIT - 1) BPP_STAMP(p, 10);

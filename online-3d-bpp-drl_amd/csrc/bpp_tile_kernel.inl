@@ -113,6 +113,19 @@ struct TileGeo {
     static_assert(NB <= kWave && LPB >= 1 && (EPW & (EPW - 1)) == 0 && (NIT & (NIT - 1)) == 0, "bins per workgroup");
 };
 
+// Observation and mask go out as 16-byte stores.  For the 20x20 bins they are NONTEMPORAL stores (global_store_dwordx4 ... nt):
+// a lock-step of 32 768 such bins writes 263 MB, more than the Infinity Cache holds, and keeping those lines out of it is
+// worth 2.5 % (one output set) to 3.8 % (outputs rotated): 56.7 -> 55.3 / 57.6 -> 55.4 us.  The 10x10 bins lose with them
+// (28.4 -> 36.6 us: their 133 MB per lock-step is what the cache absorbs) -- profiles/r4zm_*, r4zn_*.
+#if defined(__clang__)
+typedef float bpp_v4f __attribute__((ext_vector_type(4)));
+#else
+typedef float bpp_v4f __attribute__((vector_size(16)));   // (the host emulator's compiler)
+#endif
+__device__ __forceinline__ void store_out4_nt(float4 *dst, float a, float b, float c, float d) {
+    __builtin_nontemporal_store((bpp_v4f){a, b, c, d}, (bpp_v4f *)dst);
+}
+
 // The kernel itself, in its two forms (bpp_tile_body.inl).
 #define BPP_TILE_NAME bpp_tile_kernel
 #define BPP_TILE_CACHE false

@@ -203,6 +203,8 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t se
 }
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T>
+static inline void __builtin_nontemporal_store(T v, T *p) { *p = v; }   // a cache hint of the product's output stores: nothing to emulate
 extern long long g_emu_cache_stat[2];   // [0] look-aheads read from the ring, [1] answered by the row cache (bpp_batch.seq_cache)
 #define BPP_CACHE_STAT(hit) ((void)(g_emu_cache_stat[(hit) ? 1 : 0]++))
 #define BPP_DRAIN_VMEM() ((void)0)   // the product's `s_waitcnt vmcnt(0)` (inline gfx950 asm): nothing to drain here
