@@ -1875,56 +1875,55 @@ __global__ __launch_bounds__(BPP_REDUCE_LANES) void acc_reduce_kernel(double *ep
 // The same reduction spread over the chip (bpp_episode_acc_reduce with a scratch buffer).  The normative order has 1 024
 // partial sums, each ONE sequential chain over its strided rows -- so 1 024 lanes is all the parallelism there is, and in
 // one workgroup they share one CU's memory pipeline (2 MB at ~30 GB/s).  Here every workgroup owns kAccWideLanes of the
-// partials (16 consecutive rows = one 512-byte line group per load instruction), keeps kAccWideU rows per lane in
-// flight, publishes its partials to the caller's scratch buffer and takes a ticket; the last arriver runs the binary
+// partials (16 consecutive rows = one 512-byte line group per load instruction), fetches kAccWideRows rows of each at
+// once with all its threads, publishes its partials to the caller's scratch buffer and takes a ticket; the last arriver runs the binary
 // tree over all 1 024 partials.  Hand-off per MI355X_MICROARCH.md (inter-workgroup visibility): plain stores ->
 // __syncthreads -> lane-0 agent-scope release -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer: agent-scope
 // acquire behind the ticket -> __syncthreads -> plain loads.
 #ifndef BPP_DRAIN_VMEM   // (the host emulator of tests/emu defines it away: there is no vector memory queue to drain)
 #define BPP_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // invisible to the compiler's waitcnt pass, which may drop its own
 #endif
-constexpr int kAccWideLanes = 16, kAccWideGroups = BPP_REDUCE_LANES / kAccWideLanes, kAccWideU = 16;
+constexpr int kAccWideLanes = 16, kAccWideGroups = BPP_REDUCE_LANES / kAccWideLanes, kAccWideRows = 64;
 __global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, int E, double *acc, int clear, double *scratch) {
     static __shared__ double part[4][BPP_REDUCE_LANES];
     static __shared__ int last;
     const int t = threadIdx.x;
     unsigned int *ticket = (unsigned int *)(scratch + 4 * BPP_REDUCE_LANES);
-    if (t < kAccWideLanes) {
-        const int r = blockIdx.x * kAccWideLanes + t;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int e = r;
-        for (; e + (kAccWideU - 1) * BPP_REDUCE_LANES < E; e += kAccWideU * BPP_REDUCE_LANES) {
-            double v[kAccWideU][4];
+    // All 256 threads fetch: thread (j, l) = (t / 16, t % 16) brings rows j, j + 16, j + 32, j + 48 of a chunk of 64 rows of
+    // partial l into LDS (`part` is free until the tree) -- one memory latency per chunk instead of one per kAccWideU rows
+    // of a lane's own chain; then 64 threads, one per (partial, component), add the chunk's 64 values IN ROW ORDER: the same
+    // additions in the same order as the one-workgroup kernel (a row beyond E is read as +0.0, which changes no sum that
+    // started from +0.0).
+    {
+        double (*rows)[kAccWideLanes][4] = (double (*)[kAccWideLanes][4]) & part[0][0];     // [64][16][4] = 32 KB
+        const int l = t % kAccWideLanes, j = t / kAccWideLanes;
+        const int r = blockIdx.x * kAccWideLanes + l;
+        const int al = t / 4 % kAccWideLanes, ak = t % 4;      // adder thread t < 64: partial al, component ak
+        double sum = 0.0;
+        for (int e0 = 0; e0 < E; e0 += kAccWideRows * BPP_REDUCE_LANES) {
+            double v[kAccWideRows / 16][4];
 #pragma unroll
-            for (int u = 0; u < kAccWideU; ++u) {
-                const double *a = (const double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
-                v[u][0] = a[0], v[u][1] = a[1], v[u][2] = a[2], v[u][3] = a[3];
-            }
-#pragma unroll
-            for (int u = 0; u < kAccWideU; ++u) {
-                s0 = s0 + v[u][0];
-                s1 = s1 + v[u][1];
-                s2 = s2 + v[u][2];
-                s3 = s3 + v[u][3];
-                if (clear) {
-                    double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
-                    a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
+            for (int m = 0; m < kAccWideRows / 16; ++m) {
+                const int e = e0 + (j + 16 * m) * BPP_REDUCE_LANES + r;
+                v[m][0] = v[m][1] = v[m][2] = v[m][3] = 0.0;
+                if (e < E) {
+                    double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
+                    v[m][0] = a[0], v[m][1] = a[1], v[m][2] = a[2], v[m][3] = a[3];
+                    if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
                 }
             }
+#pragma unroll
+            for (int m = 0; m < kAccWideRows / 16; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rows[j + 16 * m][l][k] = v[m][k];
+            __syncthreads();
+            if (t < 4 * kAccWideLanes) {
+#pragma unroll 8
+                for (int q = 0; q < kAccWideRows; ++q) sum = sum + rows[q][al][ak];
+            }
+            __syncthreads();
         }
-        for (; e < E; e += BPP_REDUCE_LANES) {
-            double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
-            const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
-            s0 = s0 + v0;
-            s1 = s1 + v1;
-            s2 = s2 + v2;
-            s3 = s3 + v3;
-            if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
-        }
-        scratch[0 * BPP_REDUCE_LANES + r] = s0;
-        scratch[1 * BPP_REDUCE_LANES + r] = s1;
-        scratch[2 * BPP_REDUCE_LANES + r] = s2;
-        scratch[3 * BPP_REDUCE_LANES + r] = s3;
+        if (t < 4 * kAccWideLanes) scratch[ak * BPP_REDUCE_LANES + blockIdx.x * kAccWideLanes + al] = sum;
     }
     __syncthreads();
     if (t == 0) {
