@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 13
+#define BPP_ABI_VERSION 14
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -155,6 +155,11 @@ typedef struct bpp_batch {
  *     below(lim), the n-th draw of the sequence (random.choice(flags) = flags[below(len)], random.randint(1, v) = 1 +
  *     below(v)):  a = 0;  m = (uint64)word(n, a) * lim;  if (uint32)m < lim:  t = (2^32 - lim) mod lim;  while (uint32)m <
  *     t:  a += 1, m = (uint64)word(n, a) * lim;   result = m >> 32          (Lemire's unbiased multiply-shift)
+ * (The per-stream key passes through ONE 32-bit hash h and every word is one fmix32 permutation of a 32-bit input: keys
+ * are distinct for sid < 2^32 under one seed, but all bins draw from the same 2^32-point function at structured offsets --
+ * the quality of the streams rests on fmix32's avalanche alone.  Accepted for a benchmark / training item supply; checked
+ * by the distribution test and by tests/test_stream_counter.py's correlation test across neighbouring bins, episodes and
+ * draws.  Not a cryptographic or a 2^64-period generator.)
  * A bin's record is then 16 bytes: its stream id (copied with the record when a bin is cloned, so that the copy
  * continues the SOURCE's stream).  Uniformity of every draw is what makes the distribution of sequences the
  * reference's; tests/test_stream_counter.py compares item-size and sequence-length statistics of the two generators. */
@@ -281,6 +286,17 @@ int bpp_mask_from_hmap(const int32_t *hmap, const int32_t *items, float *mask, i
 int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t M, int64_t env_id_base,
                         uint64_t seed, uint64_t step, void *stream);
 
+/* Failure-path variant of that action source (SURVEY.md 8d "variant: epsilon = 1 % uniformly random over all actions to
+ * exercise the failure path"; no reference counterpart): with probability eps_q24 / 2^24 the action of bin e is REPLACED by a
+ * uniform draw over all M entries, feasible or not.  Normative: with hash32 the function of bpp_sample_feasible,
+ *     coin = hash32(seed ^ BPP_EPS_KEY_COIN, global bin id, step) >> 8;   if coin < eps_q24:
+ *     actions[e] = (hash32(seed ^ BPP_EPS_KEY_PICK, global bin id, step) * M) >> 32
+ * so a (seed, step) pair used for bpp_sample_feasible can be reused here.  eps_q24 in 0 .. 2^24; 0 enqueues nothing. */
+#define BPP_EPS_KEY_COIN 0x5851F42D4C957F2DULL
+#define BPP_EPS_KEY_PICK 0xDA942042E4DD58B5ULL
+int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed, uint64_t step,
+                         uint32_t eps_q24, void *stream);
+
 /* Masked categorical action selection of the policy head, fused.  Replaces the
  * inference half of acktr.distributions.Categorical.forward (acktr/distributions.py:71-84) as used by
  * Policy.act (acktr/model.py:56-68) after the linear layer:
@@ -373,6 +389,10 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
  * call) -- the call then enqueues exactly nsteps launches of the step kernel and nothing else; without it the first
  * action is drawn from `first_mask`, the mask of the current observations (as left by bpp_reset / bpp_step). */
 #define BPP_ROLLOUT_CONTINUE 1
+/* flags bits 8..31: epsilon of SURVEY.md 8d's failure-path variant as a 24-bit fraction (BPP_ROLLOUT_EPS(0.01 * 2^24) = 1 %):
+ * every draw is followed by bpp_epsilon_override with the draw's own (seed, step).  0 = the plain uniform-feasible policy. */
+#define BPP_ROLLOUT_EPS(q24)      ((int32_t)((uint32_t)(q24) << 8))
+#define BPP_ROLLOUT_EPS_OF(flags) ((uint32_t)(flags) >> 8)
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream);
 

@@ -179,6 +179,13 @@ __device__ __forceinline__ void row_cache_drop(const Params &p, int e) {
 // requests per iteration, in rounds of 64 whose ring reads are ALL issued before the first line is written -- the reads miss
 // every cache, a round costs one such latency (15-18 us), and a round is all a wave ever needs in practice.  Few, fat copier
 // workgroups: each holds one of its CU's eight workgroup slots for that long.
+// Ordering: a copier may read req[e] in the SAME launch in which the bin's step workgroup posts it (nothing
+// orders the two inside a launch) and then builds the line one launch early.  That is benign by construction: (i) the line
+// it writes is the bin's OTHER line, which the deciding phase does not read before the launch after next (pending 1 -> 2 ->
+// switch), whoever wrote it and when; (ii) what it reads exists: a line for row k + 1 holds entries of rows k + 1 and k + 2,
+// whose look-ahead headers were completed when rows k + 3 and k + 4 were cut, and with a row cache the refill schedule
+// (every depth - 4 lock-steps) guarantees rows up to episode + 4 at the START of every launch -- the launch in which a bin of
+// episode k posts the request included; the regular service one launch later has a row to spare.
 constexpr int kCopierBins = 4 * 256;
 __device__ __forceinline__ void wave_sync();
 __device__ __forceinline__ void row_cache_copier(const Params &p, int e_wave, uint32_t *list) {
@@ -2315,6 +2322,16 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     return 0;
 }
 
+// bpp_epsilon_override (include/bpp_abi.h): with probability eps_q24 / 2^24 a bin's action becomes a uniform draw over ALL M
+// entries -- SURVEY 8d's failure-path variant of the benchmark policy.  One thread per bin.
+__global__ void eps_override_kernel(int64_t *actions, int E, int M, int64_t env_id_base, uint64_t seed, uint64_t step, uint32_t eps_q24) {
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= E) return;
+    const uint32_t gid = (uint32_t)(env_id_base + e);
+    const uint32_t h = mix32(mix32_base(seed ^ BPP_EPS_KEY_COIN, step), gid);
+    if ((h >> 8) < eps_q24) actions[e] = (int64_t)__umulhi(mix32(mix32_base(seed ^ BPP_EPS_KEY_PICK, step), gid), (uint32_t)M);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2462,6 +2479,17 @@ int bpp_sample_feasible(const float *mask, int64_t *actions, int32_t E, int32_t 
         hipLaunchKernelGGL(sample_kernel_generic, dim3((E + 3) / 4), dim3(256), 0, st, mask, actions, E, M, env_id_base,
                            seed, step);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed, uint64_t step, uint32_t eps_q24,
+                         void *stream) {
+    if (!actions) return fail(BPP_E_BADARG, "bpp_epsilon_override: NULL pointer");
+    if (E <= 0 || M <= 0 || eps_q24 > (1u << 24)) return fail(BPP_E_BADARG, "bpp_epsilon_override: bad size / eps_q24 > 2^24");
+    if (eps_q24 == 0) return 0;
+    hipLaunchKernelGGL(eps_override_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions, E, M, env_id_base, seed,
+                       step, eps_q24);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
 }
@@ -2656,10 +2684,13 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
         if (!outs[k].mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: every output set needs a mask");
     if (nsteps == 0) return 0;
     const int M = b->W * b->L * (1 + b->rotation);
+    const uint32_t eps = BPP_ROLLOUT_EPS_OF(flags);     // SURVEY 8d's failure-path variant: one tiny launch behind every draw
+    if (eps > (1u << 24)) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: epsilon > 1");
     int rc = 0;
     if (!(flags & BPP_ROLLOUT_CONTINUE)) {
         if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");
         rc = bpp_sample_feasible(first_mask, actions, b->num_envs, M, b->env_id_base, seed, step0, stream);
+        if (rc == 0 && eps) rc = bpp_epsilon_override(actions, b->num_envs, M, b->env_id_base, seed, step0, eps, stream);
     }
     for (int t = 0; rc == 0 && t < nsteps; ++t) {
         bpp_step_out o = outs[t % nsets];
@@ -2667,6 +2698,7 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
         o.sample_seed = seed;
         o.sample_step = step0 + (uint64_t)t + 1;
         rc = bpp_step(b, actions, &o, stream);
+        if (rc == 0 && eps) rc = bpp_epsilon_override(actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t + 1, eps, stream);
     }
     return rc;
 }

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
     if constexpr (CACHE) {
         if ((int)blockIdx.x < p.ncopy) {               // copier workgroup: serves the refresh requests of kCopierBins bins, nothing else
             static_assert(T::LDS_WAVE >= 3 * 4 * 256, "a copier wave lists up to 256 requests in its LDS area");
+            static_assert(kCopierBins == kTileWaves * 4 * kWave, "a copier workgroup's waves serve 4 x 64 bins each (row_cache_copier): every bin of the workgroup must have a wave");
             row_cache_copier(p, (int)blockIdx.x * kCopierBins + wid * (kCopierBins / kTileWaves), (uint32_t *)(smem + wid * T::LDS_WAVE));
             return;
         }
@@ -423,12 +424,12 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
         const bool draw = MODE == kStep && p.next_action != nullptr;
         // per (bin, orientation) constants, one lane per slot (lane sl == rot of bin el), all bins of the group at once;
         // they stay in this lane's registers and are read with v_readlane by the candidate loop
-        uint32_t slotw[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        uint32_t slotw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         constexpr bool kResets = kDecide;                      // a bin that was just reset
         constexpr bool kResetsOnly = MODE == kResetInit || MODE == kResetAdvance;   // every bin shows an empty map
         if (EPW > 1 && mine && sl < (ROT ? 2 : 1)) {           // shows an empty map: its mask is the in-range rectangle
             make_slot_words<W, L>(myrec.item, sl, kResets && (myrec.flags & 2u) != 0u, ROT, p.H, slotw);
-            slotw[6] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
+            slotw[7] = draw ? mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + el)) : 0u;
         }
 
         if (MODE == kStep) {
@@ -577,23 +578,24 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
             for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
                 // the slot's constants, wave-uniform: read from the registers of the slot's lane -- or, when the wave
                 // owns a single bin, straight from the item on the scalar unit
-                uint32_t w0, w1, w2, w3, w4, w5;
+                uint32_t w0, w1, w2, w3, w4, w5, w6;
                 if constexpr (EPW > 1) {
                     const int src = b * G + rot;           // lane (el = b, sl = rot)
                     w0 = (uint32_t)__builtin_amdgcn_readlane(slotw[0], src), w1 = (uint32_t)__builtin_amdgcn_readlane(slotw[1], src);
                     w2 = (uint32_t)__builtin_amdgcn_readlane(slotw[2], src), w3 = (uint32_t)__builtin_amdgcn_readlane(slotw[3], src);
                     w4 = (uint32_t)__builtin_amdgcn_readlane(slotw[4], src), w5 = (uint32_t)__builtin_amdgcn_readlane(slotw[5], src);
+                    w6 = (uint32_t)__builtin_amdgcn_readlane(slotw[6], src);
                 } else {
                     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].item);
                     const uint32_t flg = (uint32_t)__builtin_amdgcn_readfirstlane(rec[b].flags);
-                    uint32_t ww[6];
+                    uint32_t ww[7];
                     make_slot_words<W, L>(item, rot, kResets && (flg & 2u) != 0u, ROT, p.H, ww);
-                    w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4], w5 = ww[5];
+                    w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4], w5 = ww[5], w6 = ww[6];
                     if (rot == 0 && draw) hsh = mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e0 + b));
                 }
                 const uint32_t od = w0;
-                const int nj = (int)((w1 >> 11) & 31u), nv = (int)(w1 & 0x7ffu), hz1 = (int)((w1 >> 16) & 0x1ffu);
-                const bool valid = (w1 >> 28) & 1u, big = (w1 >> 29) & 1u, fresh = (w1 >> 30) & 1u, square = (w1 >> 31) & 1u;
+                const int nj = (int)((w1 >> 11) & 31u), nv = (int)(w1 & 0x7ffu), hz1 = (int)((w6 >> 16) & 0x1ffu);
+                const bool valid = (w1 >> 28) & 1u, big = (w1 >> 29) & 1u, fresh = (w6 >> 30) & 1u, square = ((w1 & w6) >> 31) & 1u;
                 const int xPW = (int)(w2 & 0xffffu), y = (int)(w2 >> 16), x = (int)((w5 >> 16) & 255u);
                 const int o10 = (int)(w3 & 0xffffu), o01 = (int)(w3 >> 16);
                 const int t95 = (int)(w4 & 0xffffu), t85 = (int)(w4 >> 16), t50 = (int)(w5 & 0xffffu);
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
             // enumerated in index order, first orientation first); all-ones fallback: pick among all M entries.
             if (draw) {
                 const int e = e0 + b;
-                if constexpr (EPW > 1) hsh = (uint32_t)__builtin_amdgcn_readlane(slotw[6], b * G);
+                if constexpr (EPW > 1) hsh = (uint32_t)__builtin_amdgcn_readlane(slotw[7], b * G);
                 if (tot == 0) {
                     if (lane == 0) p.next_action[e] = (int64_t)__umulhi(hsh, (uint32_t)M);
                 } else {

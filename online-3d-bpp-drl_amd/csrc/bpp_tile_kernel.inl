@@ -44,11 +44,12 @@ constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
 // (lane sl == orientation of bin el holds the slot's seven words in registers) and read back wave-uniformly by the
 // candidate loop with v_readlane -- no LDS round trip, ~100 scalar instructions per bin saved.
 //   w0: index-decode multiplier ceil(2^22 / nj) (23 bits)
-//   w1: nv (candidates, 11 bits) | nj << 11 (5 bits) | hz1 << 16 (9 bits: max(H - z + 1, 0)) | valid << 28 | big << 29 | fresh << 30 | square << 31
+//   w1: nv (candidates, 11 bits) | nj << 11 (5 bits) | valid << 28 | big << 29 | (x == y) << 31
 //   w2: x * PW entries (prefix-image row offset) | y << 16
 //   w3: (x - 1) * L (corner offset) | (y - 1) << 16
 //   w4: t95 | t85 << 16          w5: t50 | x << 16 | y << 24
-//   w6: hash32(seed, global bin id, step) of the fused draw
+//   w6 (per step): hz1 << 16 (9 bits: max(H - z + 1, 0)) | fresh << 30 | (second half of a rotation mask) << 31
+//   w7: hash32(seed, global bin id, step) of the fused draw
 // Per-bin record in LDS written by the deciding wave (or, in the mask-only modes, by the owning wave), read by the
 // bin's lanes: 12 bytes.
 struct TileRec {
@@ -64,28 +65,62 @@ constexpr int kLowTop = kLevelsPerWord - 1;
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
 // The six words of a slot that the candidate loop consumes, from the item on display (same code for the
-// lane-parallel and the scalar-unit evaluation).
+// lane-parallel and the scalar-unit evaluation).  Everything that depends on the footprint (x, y) alone -- the candidate
+// ranges, the index-decode multiplier, the offsets, the three integer thresholds of SURVEY.md A.3 -- comes from a table in
+// constant memory, one 32-byte entry per footprint, built at compile time for the two tile geometries (round 4 computed
+// them per launch and bin: ~60 of a wave's ~680 vector instructions, executed by 4 of its 64 lanes); what is left per slot
+// is the table index, the height bound hz1 and three flag bits.
+struct SlotEntry {
+    uint32_t w[8];   // w0 .. w5 as documented above with hz1 = 0 and fresh = 0; bit 31 of w1 = "x == y" (square candidate); w6, w7 unused
+};
 template <int W, int L>
-__device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[6]) {
+struct SlotTable {
+    SlotEntry e[(W + 1) * (L + 1)];   // entry x * (L + 1) + y; row 0 and column 0 (and entry 0 for every footprint that does not fit): "invalid"
+};
+template <int W, int L>
+constexpr SlotTable<W, L> make_slot_table() {
     constexpr int PW = L + 1;
-    const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-    const int x = rot ? iy : ix, y = rot ? ix : iy;
-    const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;   // 1 <= x <= W, 1 <= y <= L
-    const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;                     // utils.py:54-55 loop ranges
-    const uint32_t area = valid ? (uint32_t)(x * y) : 0u;
-    // floor(k * area / 20) + 1: n / 20 == n * 0xCCCD >> 20 for n < 2^16, here n <= 19 * 1024
-    const uint32_t t95 = ((19u * area * 0xCCCDu) >> 20) + 1u, t85 = ((17u * area * 0xCCCDu) >> 20) + 1u, t50 = (area >> 1) + 1u;
-    const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
-    const bool big = x > kTileX || y > kTileY;
-    const bool square = rot_kernel && rot == 1 && x == y && valid;
-    // w0 is the table entry AS LOADED -- nothing is computed from it here, so that the load's latency is only waited for
-    // where the candidate loop reads the word (behind the observation store and the prefix image), not in this phase
-    w[0] = kCandMagic.v[nj];
-    w[1] = (uint32_t)nv | ((uint32_t)nj << 11) | (hz1 << 16) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)fresh << 30) | ((uint32_t)square << 31);
-    w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
-    w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
-    w[4] = t95 | (t85 << 16);
-    w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+    SlotTable<W, L> t{};
+    for (int x = 0; x <= W; ++x)
+        for (int y = 0; y <= L; ++y) {
+            SlotEntry &s = t.e[x * (L + 1) + y];
+            const bool valid = x >= 1 && y >= 1;
+            const uint32_t nj = valid ? (uint32_t)(L - y + 1) : 1u, nv = valid ? (uint32_t)(W - x + 1) * nj : 0u;   // utils.py:54-55 loop ranges
+            const uint32_t area = valid ? (uint32_t)(x * y) : 0u;
+            // floor(k * area / 20) + 1
+            const uint32_t t95 = 19u * area / 20u + 1u, t85 = 17u * area / 20u + 1u, t50 = (area >> 1) + 1u;
+            const bool big = x > kTileX || y > kTileY;
+            s.w[0] = ((1u << kCandShift) + nj - 1u) / nj;
+            s.w[1] = nv | (nj << 11) | ((uint32_t)valid << 28) | ((uint32_t)(valid && big) << 29) | ((uint32_t)(valid && x == y) << 31);
+            s.w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
+            s.w[3] = (uint32_t)(x > 0 ? (x - 1) * L : 0) | ((uint32_t)(y > 0 ? y - 1 : 0) << 16);
+            s.w[4] = t95 | (t85 << 16);
+            s.w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+            s.w[6] = 0u;
+            s.w[7] = 0u;
+        }
+    return t;
+}
+__constant__ const SlotTable<10, 10> kSlotTable10 = make_slot_table<10, 10>();
+__constant__ const SlotTable<20, 20> kSlotTable20 = make_slot_table<20, 20>();
+
+template <int W, int L>
+__device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[7]) {
+    static_assert((W == 10 && L == 10) || (W == 20 && L == 20), "a slot table exists for the tile geometries only");
+    const uint32_t ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
+    const uint32_t x = rot ? iy : ix, y = rot ? ix : iy;
+    const bool fits = x <= (uint32_t)W && y <= (uint32_t)L;                   // (x == 0 or y == 0: an "invalid" entry of the table)
+    const uint32_t at = fits ? x * (uint32_t)(L + 1) + y : 0u;
+    const SlotEntry *ent;
+    if constexpr (W == 10) ent = &kSlotTable10.e[at];
+    else ent = &kSlotTable20.e[at];
+    // w0 .. w5 are the entry AS LOADED -- nothing is computed from them here, so that the loads' latency is only waited for
+    // where the candidate loop reads the words (behind the observation store and the prefix image), not in this phase;
+    // what depends on the step (z, a fresh bin, which half of a rotation mask) travels in a word of its own
+    const uint4 lo = *(const uint4 *)&ent->w[0];
+    const uint2 hi = *(const uint2 *)&ent->w[4];
+    w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w, w[4] = hi.x, w[5] = hi.y;
+    w[6] = ((uint32_t)max(H - (int)z + 1, 0) << 16) | ((uint32_t)fresh << 30) | ((uint32_t)(rot_kernel && rot == 1) << 31);
 }
 
 template <int W, int L, int K, bool ROT, int EPW, int NIT>

@@ -4,13 +4,17 @@
 
 Pass `stream=dict(bound=(lo, hi), seed=s, depth=D)` instead of a pool for the endless device-generated CUT-2 supply.
 `args` is the reference's argparse namespace (acktr/arguments.py): `container_size`, `enable_rotation`,
-`data_type` ('cut1' | 'cut2' | 'rs', bin3D.py:21-32) and `box_size_set` are honoured; `gamma`, `log_dir`,
+`data_type` ('cut1' | 'cut2' | 'rs', bin3D.py:21-32) and `box_size_set` are honoured; `gamma`,
 `allow_early_resets`, `num_frame_stack` are accepted for signature compatibility (the reference disables
-VecNormalize's filters anyway, acktr/envs.py:112; Monitor csv files are not written -- episode
-statistics come from `infos`/`EpisodeStats`).  Unlike the reference, `seed` really seeds the item
+VecNormalize's filters anyway, acktr/envs.py:112).  `log_dir` (acktr/envs.py:54-58 wraps every worker in
+`bench.Monitor(env, os.path.join(log_dir, str(rank)))`): when given, `step()` appends the finished episodes to
+`<log_dir>/<shard rank>.monitor.csv` in Monitor's format -- ONE file per shard with an extra `bin` column instead of one file
+per bin (vec_env.MonitorCsv; the reference's `bench.load_results(log_dir)` reads it); `log_dir=None` writes nothing.  The
+tensor-native `step_tensors` path never writes rows (episode statistics there come from `EpisodeStats`).
+Unlike the reference, `seed` really seeds the item
 sequences (the reference's `env.seed` is a no-op and its forked workers all draw the same stream)."""
 from . import sequences
-from .vec_env import BppVecEnv
+from .vec_env import BppVecEnv, MonitorCsv
 
 
 def make_pool(container_size, data_type="cut2", box_size_set=None, enable_rotation=False, seed=0, pool_size=4096):
@@ -43,6 +47,9 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
     env_kwargs.setdefault("fresh_outputs", True)   # reference semantics: earlier results stay valid
     env = BppVecEnv(int(num_processes), size, enable_rotation=rot, pool=pool, device=device, **env_kwargs)
     env.venv = _vec_normalize_holder()
+    if log_dir is not None:     # acktr/envs.py:54-58
+        env.monitor = MonitorCsv(log_dir, rank=env.env_id_base // max(env.E, 1), env_id=env_name, env_id_base=env.env_id_base,
+                                 t_start=env._tstart)
     return env
 
 

@@ -22,6 +22,9 @@ from .spaces import Box, Discrete
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 STATE_FORMAT = 1      # state_dict()["format"]: 1 = 48-byte records whose last word is hmax, per-bin ep_acc rows
+STREAM_LAYOUT = 2     # state_dict()["stream_layout"]: layout of the ring rows and generator records of a streaming env.
+#                       2 = ring rows start with two look-ahead entries, item i at entry 2 + i; byte-output MT19937 records /
+#                       16-byte counter records (ABI v12+).  A checkpoint without the key (layout 1 or older) is refused.
 
 
 class StepTensors(object):
@@ -216,6 +219,46 @@ class LazyInfos(object):
         return np.flatnonzero(self._done_mask())
 
 
+class MonitorCsv(object):
+    """`<log_dir>/<rank>.monitor.csv` in the format of baselines/bench/monitor.py:99-119 (ResultsWriter): a `# {json}` header
+    line with `t_start` and `env_id`, the csv header `r,l,t` + extra keys, one row per finished episode with Monitor's
+    values (`r` = round(sum of rewards, 6), `l` = steps incl. the failing one, `t` = seconds since t_start, :58-66).  The
+    reference writes one file PER WORKER (acktr/envs.py:54-58: os.path.join(log_dir, str(rank))); here all bins of a shard
+    live in one process, so there is ONE file per shard -- named after the shard's rank -- with the extra column `bin`
+    (global bin id; Monitor's own extra-key mechanism, info_keywords), and the reference's `load_results(log_dir)` reads it.
+    Rows of one lock-step are written in bin order."""
+    EXT = "monitor.csv"
+
+    def __init__(self, log_dir, rank=0, env_id="Bpp-v0", env_id_base=0, t_start=None):
+        import json
+        import os
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "%d.%s" % (int(rank), self.EXT))
+        self.t_start = time.time() if t_start is None else float(t_start)
+        self.env_id_base = int(env_id_base)
+        self.rows = 0
+        self.f = open(self.path, "wt")
+        self.f.write("# %s \n" % json.dumps({"t_start": self.t_start, "env_id": env_id}))     # monitor.py:109-111
+        self.f.write("r,l,t,bin\r\n")                                                        # csv.DictWriter.writeheader
+        self.f.flush()
+
+    def write(self, episodes, t_now=None):
+        """episodes: LazyInfos.episodes() of one lock-step (arrays bins / r / l)."""
+        n = len(episodes["bins"])
+        if n and self.f is not None:
+            t = repr(round((time.time() if t_now is None else t_now) - self.t_start, 6))
+            base = self.env_id_base
+            self.f.write("".join("%r,%d,%s,%d\r\n" % (r, l, t, base + b)
+                                 for r, l, b in zip(episodes["r"].tolist(), episodes["l"].tolist(), episodes["bins"].tolist())))
+            self.f.flush()
+            self.rows += n
+
+    def close(self):
+        if self.f is not None:
+            self.f.close()
+            self.f = None
+
+
 def copy_bin_records(hmap, state, src, dst, ring=None, mt=None, gen_next=None, depth=None):
     """Bins `dst` become copies of bins `src` (int64 index tensors on the tensors' device): byte heightmap [E][A] and
     the 48-byte record as int32 [E][12].  Streaming supply (ring [depth * E][T][4], generator records mt [E][*], gen_next
@@ -252,8 +295,10 @@ class BppVecEnv(object):
                     yields through the reference's MDlayerBoxCreator, so no sequence is ever replayed.
                     rng="counter": the same cutting algorithm on a counter-based generator (distribution parity,
                     SURVEY 8f2's bar; no per-bin state, no regeneration kernel -- the fast supply).  The ring
-                    is refilled every R <= D - 3 lock-steps (default D = 8, R = 5); `rollout_uniform` runs the
-                    refills beside the lock-steps when D >= 2 R + 3 (e.g. D = 32, R = 14).  Costs 6.6 KB of
+                    is refilled every R <= D - 3 lock-steps, R <= D - 4 with the row cache (default D = 8: R = 4 for
+                    the 10x10 / 20x20 bins, whose tile step kernel keeps a row cache by default -- cache=True / False
+                    overrides --, R = 5 for every other geometry); `rollout_uniform` runs the refills beside the
+                    lock-steps when D >= 2 R + 3 (+ 4 with the cache; e.g. D = 32, R = 14).  Costs 6.6 KB of
                     generator state per bin (16 bytes with rng="counter") plus D rows of W*L*H / lo^3 + 3 entries.
     """
 
@@ -303,9 +348,10 @@ class BppVecEnv(object):
                 # schedule leaves that row
                 if stream.get("cache") is not None:
                     cache = bool(stream["cache"])
-                else:
+                else:       # only the tile step kernel keeps the cache: any other geometry would pay a row of look-ahead for nothing
                     cache = depth >= 5 and depth - int(stream.get("refill_every", 1)) >= 4 and \
-                        int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3)) < 8192
+                        int(stream.get("pool_len", self.W * self.L * self.H // lo ** 3 + 3)) < 8192 and \
+                        _lib.launch_info(self.E, self.bin_size, self.can_rotate)["kernel"] == 2      # BPP_KERNEL_TILE
                 behind = 4 if cache else 3
                 if depth < behind + 1:
                     raise ValueError("stream depth must be >= %d" % (behind + 1))
@@ -359,6 +405,7 @@ class BppVecEnv(object):
         self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
         self._tstart = time.time()
+        self.monitor = None        # MonitorCsv (make_vec_envs with a log_dir): step_wait() appends the finished episodes' rows
         self.closed = False
 
     MAX_STAGING = 16     # page-locked host buffers (29 B per bin each) handed out at the same time, at most
@@ -630,10 +677,12 @@ class BppVecEnv(object):
         """`n` complete sets of output buffers for rollout_uniform_sets (lock-step t writes set t mod n)."""
         return [self._alloc() for _ in range(int(n))]
 
-    def rollout_uniform_sets(self, seed, step0, nsteps, actions, sets=None, resume=False):
+    def rollout_uniform_sets(self, seed, step0, nsteps, actions, sets=None, resume=False, eps=0.0):
         """bpp_rollout_uniform_sets: like rollout_uniform, but lock-step t writes its outputs into sets[t mod n]
         (output_sets(n); default: the env's own single set) and the LAST lock-step also draws the next action, so that
         a following call with resume=True enqueues nothing but its `nsteps` step-kernel launches.  Finite pools only.
+        eps > 0: SURVEY 8d's failure-path variant -- every draw is followed by bpp_epsilon_override (with probability eps
+        the action becomes a uniform draw over ALL entries; one more tiny launch per lock-step).
         Returns the StepTensors of the last lock-step."""
         if self._first_reset:
             raise RuntimeError("call reset() before rollout_uniform_sets()")
@@ -652,7 +701,8 @@ class BppVecEnv(object):
         self._serial += int(nsteps)
         _lib.check(self.lib.bpp_rollout_uniform_sets(self._batch_ref, outs, n, first.data_ptr() if first is not None else None,
                                                      actions.data_ptr(), int(seed), int(step0), int(nsteps),
-                                                     _lib.ROLLOUT_CONTINUE if resume else 0, self._stream_ptr()))
+                                                     (_lib.ROLLOUT_CONTINUE if resume else 0) | (_lib.rollout_eps_flags(eps) if eps else 0),
+                                                     self._stream_ptr()))
         if nsteps > 0:
             self._bufs, self._out = sets[(int(nsteps) - 1) % n]
             self._res = self._bufs
@@ -682,13 +732,19 @@ class BppVecEnv(object):
             rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
             done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
-        return r.obs, reward, done, LazyInfos(self, r, time.time(), done=done, serial=self._serial)
+        t_now = time.time()
+        infos = LazyInfos(self, r, t_now, done=done, serial=self._serial)
+        if self.monitor is not None and done.any():         # bench/monitor.py:58-72: a row per finished episode
+            self.monitor.write(infos.episodes(), t_now)
+        return r.obs, reward, done, infos
 
     def step(self, actions, sample=None):
         self.step_async(actions, sample=sample)
         return self.step_wait()
 
     def close(self):
+        if self.monitor is not None:
+            self.monitor.close()
         self.closed = True
 
     def render(self, mode="human"):
@@ -715,6 +771,16 @@ class BppVecEnv(object):
         if rc:
             _lib.check(rc)
         return out
+
+    def epsilon_override(self, actions, seed, step, eps):
+        """bpp_epsilon_override on an int64 [E] device tensor of actions, in place: with probability `eps` a bin's action
+        becomes a uniform draw over all act_len entries (the failure-path variant of the benchmark policy)."""
+        if actions.device != self.device or actions.dtype != torch.int64 or actions.numel() != self.E or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous int64 [E] tensor on the env's device")
+        self._on_device()
+        _lib.check(self.lib.bpp_epsilon_override(actions.data_ptr(), self.E, self.M, self.env_id_base, int(seed), int(step),
+                                                 _lib.eps_q24(eps), self._stream_ptr()))
+        return actions
 
     def episode_stats(self, reset=False, wide=True, out=None):
         """float64 [4] device tensor: sum of episode returns, sum of final ratios, sum of episode lengths,
@@ -816,7 +882,7 @@ class BppVecEnv(object):
               "first_reset": self._first_reset}
         if self._stream is not None:   # streaming supply: the ring, every bin's generator and its progress
             sd.update(stream_ring=self.pool.clone(), stream_mt=self._mt.clone(), stream_gen_next=self.gen_next.clone(),
-                      stream_since_refill=self._since_refill, stream_spec=self._stream_identity())
+                      stream_since_refill=self._since_refill, stream_spec=self._stream_identity(), stream_layout=STREAM_LAYOUT)
         if self._bufs is not None:
             sd["obs"] = self._bufs["obs"].clone()
             if self._bufs["mask"] is not None:
@@ -835,6 +901,9 @@ class BppVecEnv(object):
         if self._stream is not None:
             if "stream_ring" not in sd:
                 raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
+            if int(sd.get("stream_layout", 1)) != STREAM_LAYOUT:
+                raise ValueError("streaming checkpoint with ring / generator layout %d, this build reads layout %d: its rows would be "
+                                 "played as other items" % (int(sd.get("stream_layout", 1)), STREAM_LAYOUT))
             want, got = self._stream_identity(), sd.get("stream_spec")
             if got is not None:
                 got = dict(got)

@@ -506,15 +506,31 @@ int bpp_wait(void *stream) {
     return 0;
 }
 
+int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed, uint64_t step, uint32_t eps_q24,
+                         void *stream) {
+    (void)stream;
+    if (!actions) return fail(BPP_E_BADARG, "bpp_epsilon_override: NULL pointer");
+    if (E <= 0 || M <= 0 || eps_q24 > (1u << 24)) return fail(BPP_E_BADARG, "bpp_epsilon_override: bad size / eps_q24 > 2^24");
+    for (int e = 0; e < E; ++e) {      /* include/bpp_abi.h: coin and pick are two independent hashes of (seed, bin, step) */
+        uint64_t gid = (uint64_t)(env_id_base + e);
+        if ((mix32(seed ^ BPP_EPS_KEY_COIN, gid, step) >> 8) < eps_q24)
+            actions[e] = (int64_t)(((uint64_t)mix32(seed ^ BPP_EPS_KEY_PICK, gid, step) * (uint64_t)M) >> 32);
+    }
+    return 0;
+}
+
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream) {
     if (!b || !outs || !actions || nsets < 1) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: NULL pointer / no output set");
     if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: negative nsteps");
     int M = b->W * b->L * (1 + b->rotation), rc = 0;
+    uint32_t eps = BPP_ROLLOUT_EPS_OF(flags);
+    if (eps > (1u << 24)) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: epsilon > 1");
     if (nsteps == 0) return 0;
     if (!(flags & BPP_ROLLOUT_CONTINUE)) {
         if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");
         rc = bpp_sample_feasible(first_mask, actions, b->num_envs, M, b->env_id_base, seed, step0, stream);
+        if (rc == 0 && eps) rc = bpp_epsilon_override(actions, b->num_envs, M, b->env_id_base, seed, step0, eps, stream);
     }
     for (int t = 0; rc == 0 && t < nsteps; ++t) {
         bpp_step_out o = outs[t % nsets];
@@ -523,6 +539,8 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
         rc = bpp_step(b, actions, &o, stream);
         if (rc == 0)
             rc = bpp_sample_feasible(o.mask, actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t + 1, stream);
+        if (rc == 0 && eps)
+            rc = bpp_epsilon_override(actions, b->num_envs, M, b->env_id_base, seed, step0 + (uint64_t)t + 1, eps, stream);
     }
     return rc;
 }

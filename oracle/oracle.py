@@ -95,6 +95,8 @@ def lib():
         L.bpp_rollout_uniform_sets.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_int32, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_void_p]
+        L.bpp_epsilon_override.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
+                                           ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
@@ -249,7 +251,14 @@ def rollout_uniform(env, seed, step0, nsteps):
     return env.out, a
 
 
-def rollout_uniform_sets(env, seed, step0, nsteps, nsets, resume=False, actions=None, first_mask=None):
+def epsilon_override(actions, M, seed, step, eps, env_id_base=0):
+    """bpp_epsilon_override on a host int64 array, in place."""
+    a = np.ascontiguousarray(actions, dtype=np.int64)
+    _check(lib().bpp_epsilon_override(_p(a), a.shape[0], int(M), int(env_id_base), int(seed), int(step), int(round(eps * (1 << 24))), None))
+    return a
+
+
+def rollout_uniform_sets(env, seed, step0, nsteps, nsets, resume=False, actions=None, first_mask=None, eps=0.0):
     """bpp_rollout_uniform_sets on OracleEnv `env`: lock-step t writes output set t mod nsets; returns (list of the
     sets as dicts of arrays, actions = the draw for lock-step step0 + nsteps)."""
     E, A, M = env.E, env.A, env.M
@@ -261,7 +270,7 @@ def rollout_uniform_sets(env, seed, step0, nsteps, nsets, resume=False, actions=
     a = np.zeros(E, np.int64) if actions is None else actions
     fm = env.out["mask"] if first_mask is None else first_mask
     _check(lib().bpp_rollout_uniform_sets(ctypes.byref(env._b), outs, nsets, _p(fm), _p(a), int(seed), int(step0), int(nsteps),
-                                          1 if resume else 0, None))
+                                          ctypes.c_int32(((1 if resume else 0) | (int(round(eps * (1 << 24))) << 8)) & 0xFFFFFFFF).value, None))
     return sets, a
 
 

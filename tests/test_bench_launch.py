@@ -55,20 +55,44 @@ def test_self_launch_command_line(monkeypatch):
 def test_gpu_bench_two_ranks_without_a_launcher():
     """`python bench.py --gpus 2` (no torchrun): it starts its two ranks itself; on this 1-GPU box both ranks share
     device 0 (BPP_BENCH_ONE_DEVICE=1 -> gloo for the barrier and the 32-byte statistics all-reduce)."""
-    d = _run(["--gpus", "2", "--steps", "20", "--warmup", "5"], BPP_BENCH_ONE_DEVICE="1")
+    d = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--only-headline"], BPP_BENCH_ONE_DEVICE="1")
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and d["steps"] == 20 and d["warmup"] == 5
     assert d["config"]["launcher"] == "self-launched torch.distributed.run"
     assert d["value"] > 1e8 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["timed_gpu_work_ms"] >= 150.0
     assert d["config"]["episodes_finished"] > 0
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["checked_bins"] == 512      # every rank gates its own shard
+
+
+@pytest.mark.gpu
+def test_gpu_bench_eight_ranks_on_one_device_shard_by_global_id():
+    """SURVEY 8e without an 8-GPU box: `python bench.py --gpus 8 --envs 8192` self-launched, all eight ranks on device 0
+    over gloo.  Rank r owns the global bins from r * E (rank 7: 7 * 8192), the job has 65 536 bins, every rank's parity gate
+    ran on its own shard, and the all-reduced statistics record is the sum of the eight shards' fixed-order reductions
+    (counts exactly; the float sums up to the association of the seven final adds)."""
+    import numpy as np
+    d = _run(["--gpus", "8", "--envs", "8192", "--steps", "20", "--warmup", "5", "--gpu-seconds", "0.3", "--no-past-l3"],
+             BPP_BENCH_ONE_DEVICE="1")
+    assert d["n_gpus"] == 8 and d["config"]["total_envs"] == 65536 and d["config"]["envs_per_gpu"] == 8192
+    assert "8 rank(s)" in d["config"]["sharding"] and "gloo" in d["config"]["sharding"]
+    shards = d["config"]["shards"]
+    assert [s["rank"] for s in shards] == list(range(8))
+    assert [s["env_id_base"] for s in shards] == [r * 8192 for r in range(8)] and shards[7]["env_id_base"] == 7 * 8192
+    parts, whole = np.array([s["sums"] for s in shards]), np.array(d["config"]["episode_sums"])
+    assert (parts[:, 3] > 0).all()                                       # every shard finished episodes of its own
+    np.testing.assert_array_equal(parts[:, 2:].sum(axis=0), whole[2:])   # lengths and episode counts: integers, exact
+    np.testing.assert_allclose(parts[:, :2].sum(axis=0), whole[:2], rtol=1e-13, atol=0)
+    assert d["config"]["episodes_finished"] == int(whole[3])
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["checked_bins"] == 8 * 256 and d["parity"]["per_workload"]["10x10x10"]["ranks"] == 8
+    assert d["value"] > 1e8 and "cpu_baseline" not in d
 
 
 @pytest.mark.gpu
 def test_gpu_bench_spawned_single_rank_equals_direct_run():
     """N = 1 through the self-launch path gives the same line as the direct run (same workload, value within noise),
     and the line carries both roofline fractions (L3-assisted and past the Infinity Cache)."""
-    a = _run(["--steps", "100", "--warmup", "20", "--no-cpu-baseline"])
-    b = _run(["--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--launcher", "spawn"])
+    a = _run(["--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--only-headline"])
+    b = _run(["--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--only-headline", "--launcher", "spawn"])
     assert a["config"]["launcher"] == "direct" and b["config"]["launcher"] == "self-launched torch.distributed.run"
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["config"]["total_envs"] == b["config"]["total_envs"] == 65536
     assert abs(a["value"] / b["value"] - 1.0) < 0.1
@@ -78,3 +102,29 @@ def test_gpu_bench_spawned_single_rank_equals_direct_run():
         assert d["value_past_l3"] <= d["value"] * 1.05
         assert d["past_l3"]["output_span_MB"] > 1000 and d["timed_gpu_work_ms"] >= 200.0
         assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        assert "configs" not in d and d["parity"]["mismatches"] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_bench_default_line_carries_every_single_gpu_config_and_the_parity_gate():
+    """The line the driver runs (`python bench.py --gpus 1 --steps 20 --warmup 5`, here with shorter legs and without the
+    CPU baseline): value = BASELINE config 2; `configs` holds config 3 (rotation), config 4 (20x20x20, 32 768 bins) and
+    config 2 on the reference's own dataset pool, each with value, value_past_l3 and a roofline block; `parity` is the
+    in-run gate against the oracle (0 mismatches or no line at all); `epsilon_variant` is SURVEY 8d's failure-path leg."""
+    d = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--gpu-seconds", "0.6", "--extra-seconds", "0.3",
+              "--eps-seconds", "0.2"])
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] and d["config"]["envs_per_gpu"] == 65536
+    assert set(d["configs"]) == {"10x10x10_rot", "20x20x20", "10x10x10_dataset_cut2"}
+    want = {"10x10x10_rot": (3264, 65536), "20x20x20": (11264, 32768), "10x10x10_dataset_cut2": (2864, 65536)}
+    for name, c in d["configs"].items():
+        r = c["roofline"]
+        assert r["bytes_per_env_step"] == want[name][0] and ("%d envs" % want[name][1]) in c["workload"]
+        assert c["value"] > 1e8 and c["value_past_l3"] > 1e8 and 0.3 < r["frac_past_l3"] < 1.0 and 0.3 < r["frac"] < 1.05
+        assert abs(r["achieved"] - r["bytes_per_env_step"] * want[name][1] / r["launch_us"] * 1e-3) < 1e-6 * r["achieved"]
+        assert c["parity"]["mismatches"] == 0 and c["parity"]["checked_bins"] == 256 and c["parity"]["lock_steps"] >= 20
+        assert c["episodes_finished"] > 0
+    assert d["configs"]["10x10x10_dataset_cut2"]["pool_sequences"] == 2100
+    p = d["parity"]
+    assert p["mismatches"] == 0 and p["checked_bins"] == 4 * 256 and set(p["per_workload"]) == {"10x10x10"} | set(d["configs"])
+    e = d["epsilon_variant"]
+    assert e["epsilon"] == 0.01 and e["value"] > 1e8 and e["mean_episode_length"] < d["config"]["mean_episode_length"]

@@ -136,6 +136,51 @@ def test_emulated_rollout_over_rotating_output_sets(emu, oracle, variant, size, 
     np.testing.assert_array_equal(env.ep_acc, one.ep_acc)
 
 
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), True, 70), ((20, 20, 20), False, 9)])
+def test_emulated_epsilon_variant_of_the_rollout(emu, oracle, size, rot, E):
+    """SURVEY 8d's failure-path variant (BPP_ROLLOUT_EPS in bpp_rollout_uniform_sets' flags: every draw followed by
+    bpp_epsilon_override) on the product's driver == the oracle's; the override alone == its normative definition in
+    numpy; epsilon = 0 changes nothing and a large epsilon really ends episodes early."""
+    from bpp_amd import sequences
+    pool = sequences.cut2_pool(size, 16, seed=4, native=False)
+    M = size[0] * size[1] * (2 if rot else 1)
+    a0 = np.arange(E, dtype=np.int64) % M
+    np.testing.assert_array_equal(emu.epsilon_override(a0.copy(), M, 9, 4, 0.0, env_id_base=3), a0)
+    got = emu.epsilon_override(a0.copy(), M, 9, 4, 0.3, env_id_base=3)
+    np.testing.assert_array_equal(got, oracle.epsilon_override(a0.copy(), M, 9, 4, 0.3, env_id_base=3))
+
+    def h32(seed, gid, step):      # include/bpp_abi.h: the hash of bpp_sample_feasible
+        m = 0xFFFFFFFF
+        h = ((seed & m) ^ (((seed >> 32) * 0x9E3779B1) & m)) ^ ((((step & m) + (step >> 32) * 0xC2B2AE3D) * 0x27D4EB2F) & m)
+        h ^= (gid * 0x85EBCA77) & m
+        h ^= h >> 16
+        h = (h * 0x7FEB352D) & m
+        h ^= h >> 15
+        h = (h * 0x846CA68B) & m
+        return h ^ (h >> 16)
+
+    q = int(round(0.3 * (1 << 24)))
+    want = a0.copy()
+    for e in range(E):
+        if (h32(9 ^ 0x5851F42D4C957F2D, 3 + e, 4) >> 8) < q:
+            want[e] = (h32(9 ^ 0xDA942042E4DD58B5, 3 + e, 4) * M) >> 32
+    np.testing.assert_array_equal(got, want)
+    assert 0.1 * E < np.count_nonzero(got != a0) < 0.6 * E
+
+    env = emu.EmuEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    plain = oracle.OracleEnv(pool, size, rot, E, env_id_base=3, env_id_total=E + 3)
+    env.reset(), ref.reset(), plain.reset()
+    es, ea = emu.rollout_uniform_sets(env, 5, 0, 9, 2, eps=0.25)
+    rs, ra = oracle.rollout_uniform_sets(ref, 5, 0, 9, 2, eps=0.25)
+    np.testing.assert_array_equal(ea, ra)
+    for k in range(2):
+        for f in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(es[k][f], rs[k][f], err_msg="%s set %d" % (f, k))
+    oracle.rollout_uniform_sets(plain, 5, 0, 9, 2)
+    assert ref.state["episode"].sum() > plain.state["episode"].sum()      # failures ended episodes early
+
+
 @pytest.mark.parametrize("epw,wpb", [(1, 1), (1, 16), (2, 4), (8, 2), (8, 8), (16, 4), (4, 16), (64, 1)])
 def test_emulated_tuning_knobs_do_not_change_results(emu, epw, wpb):
     emu.set_knobs(bins_per_wave=epw, waves_per_group=wpb, xcd_remap=(epw + wpb) & 1)

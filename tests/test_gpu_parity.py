@@ -2,6 +2,8 @@
 vectors and vs the oracle.  Everything is bit-exact: masks, heightmaps, observations, dones, counters
 (integer/index work) AND rewards/ratios/episode returns (float64 arithmetic in the reference's
 operation order; float32 only as the final cast), so every comparison is assert_array_equal."""
+import os
+
 import numpy as np
 import pytest
 
@@ -288,7 +290,7 @@ def test_gpu_tall_20x20_bins_two_phase_scan_matches_oracle(bpp, oracle, size, ro
     assert tall_seen > E // 20, tall_seen
 
 
-def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
+def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp, tmp_path):
     """The reference-shaped entry point: make_vec_envs(...) -> step() -> (obs device f32, reward CPU f32
     [N,1], done numpy bool, infos of dicts) exactly like VecPyTorch (acktr/envs.py:170-193), replayed
     against the golden rollout recorded from the reference stack."""
@@ -297,7 +299,8 @@ def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
     g = load_golden("rollout_cut2_10_rot")
     E = g["actions"].shape[1]
     args = types.SimpleNamespace(container_size=(10, 10, 10), enable_rotation=True, data_type="cut2", box_size_set=None)
-    envs = bpp.make_vec_envs("Bpp-v0", 1, E, 1.0, "/tmp/unused", "cuda:0", False, args=args, pool=g["pool"])
+    log_dir = str(tmp_path / "log")
+    envs = bpp.make_vec_envs("Bpp-v0", 1, E, 1.0, log_dir, "cuda:0", False, args=args, pool=g["pool"])
     assert envs.num_envs == E and envs.action_space.n == 200 and envs.observation_space.shape == (400,)
     assert envs.action_space.__class__.__name__ == "Discrete"
     obs = envs.reset()
@@ -323,6 +326,14 @@ def test_gpu_dropin_make_vec_envs_returns_reference_types(bpp):
     # fresh_outputs (default of the factory): results of earlier steps are still intact
     np.testing.assert_array_equal(held[5].cpu().numpy(), g["obs"][5].astype(np.float32))
     envs.close()
+    # log_dir (acktr/envs.py:54-58): <log_dir>/0.monitor.csv holds Monitor's row of every finished episode (monitor.py:58-72)
+    lines = open(os.path.join(log_dir, "0.monitor.csv"), newline="").read().split("\r\n")
+    assert lines[0].startswith("# {") and lines[0].endswith("r,l,t,bin") and lines[-1] == ""
+    rows = [ln.split(",") for ln in lines[1:-1]]
+    want = [(g["ep_r"][t][e], g["ep_l"][t][e], e) for t in range(40) for e in range(E) if g["done"][t][e]]
+    assert len(rows) == len(want) > 0
+    for row, (r, l, e) in zip(rows, want):
+        assert float(row[0]) == r and int(row[1]) == l and int(row[3]) == e and float(row[2]) >= 0.0
 
 
 def test_gpu_dropin_infos_read_late_are_still_the_steps_own(bpp):
@@ -526,6 +537,36 @@ def test_gpu_rollout_over_rotating_output_sets(bpp, oracle, size, rot, E):
     np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
     np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
     np.testing.assert_array_equal(env.episode_stats().cpu().numpy(), ref.episode_stats())
+
+
+@pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1027), ((20, 20, 20), False, 515)])
+def test_gpu_epsilon_variant_of_the_rollout(bpp, oracle, size, rot, E):
+    """SURVEY 8d's failure-path variant (bench.py's epsilon leg): bpp_rollout_uniform_sets with BPP_ROLLOUT_EPS == the
+    oracle's statement of it; bpp_epsilon_override alone == the oracle's; eps = 0 enqueues nothing."""
+    import torch
+    pool = bpp.sequences.cut2_pool(size, 64, seed=8)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, env_id_base=11, env_id_total=E + 11)
+    ref = oracle.OracleEnv(pool, size, rot, E, env_id_base=11, env_id_total=E + 11)
+    a0 = torch.arange(E, dtype=torch.int64, device=env.device) % env.act_len
+    np.testing.assert_array_equal(env.epsilon_override(a0.clone(), 7, 3, 0.0).cpu().numpy(), a0.cpu().numpy())
+    got = env.epsilon_override(a0.clone(), 7, 3, 0.2).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.epsilon_override(a0.cpu().numpy(), env.act_len, 7, 3, 0.2, env_id_base=11))
+    assert 0.1 * E < np.count_nonzero(got != a0.cpu().numpy()) < 0.3 * E
+    env.reset(), ref.reset()
+    actions = torch.empty(E, dtype=torch.int64, device=env.device)
+    ra, r_last, t = None, None, 0
+    for n, nsets in ((7, 3), (9, 1)):
+        sets = env.output_sets(nsets) if nsets > 1 else None
+        r = env.rollout_uniform_sets(5, t, n, actions, sets=sets, resume=t > 0, eps=0.05)
+        rs, ra = oracle.rollout_uniform_sets(ref, 5, t, n, nsets, resume=t > 0, actions=ra,
+                                             first_mask=r_last["mask"] if r_last else None, eps=0.05)
+        r_last = rs[(n - 1) % nsets]
+        t += n
+        np.testing.assert_array_equal(actions.cpu().numpy(), ra)
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy(), r_last[k], err_msg=k)
+    np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    np.testing.assert_array_equal(env.ep_acc.cpu().numpy(), ref.ep_acc)
 
 
 def test_gpu_masks_property_random_geometries(bpp, oracle):

@@ -451,6 +451,16 @@ def test_gpu_stream_checkpoints_are_validated_on_load():
     with pytest.raises(ValueError, match="stream_spec"):
         bpp_amd.BppVecEnv(64, size, stream=spec, env_id_base=64, env_id_total=128).load_state_dict(sd)
     bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(sd)      # the matching env loads
+    # the ring / generator LAYOUT is versioned too -- a checkpoint of another layout (or of a build that did not
+    # record one) is refused even when every buffer happens to have the same shape
+    assert sd["stream_layout"] == bpp_amd.vec_env.STREAM_LAYOUT
+    for old in (dict(sd, stream_layout=1), {k: v for k, v in sd.items() if k != "stream_layout"}):
+        with pytest.raises(ValueError, match="layout"):
+            bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(old)
+    # ... and the automatic row cache is only switched on where the tile step kernel (10x10 / 20x20 bins) keeps it
+    assert bpp_amd.BppVecEnv(64, size, stream=dict(spec, depth=8, refill_every=3)).stream_spec["cache"] is True
+    odd = bpp_amd.BppVecEnv(64, (7, 13, 8), stream=dict(bound=(2, 4), seed=5, depth=8))
+    assert odd.stream_spec["cache"] is False and odd.refill_every == 5
 
 
 def test_emulated_row_cache_answers_the_look_aheads(emu, oracle):
