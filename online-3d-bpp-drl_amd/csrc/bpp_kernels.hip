@@ -120,6 +120,7 @@ struct Params {
     uint8_t *done;
     float *host_reward;   // mirrors of reward / done in mapped host memory, or nullptr
     uint8_t *host_done;
+    bpp_finished *host_fin;   // records of the bins that finish an episode, in mapped host memory, or nullptr
     int32_t *counter;
     double *ratio;
     double *ep_ret;
@@ -245,6 +246,13 @@ __device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, i
     a.f1 = (size_t)(ring ? seq : seq_n) * T + (ring ? 0 : min(1, T - 1));
     a.f2 = (size_t)(ring ? seq : seq_nn) * T + (ring ? 1 : 0);
     return a;
+}
+// bpp_step_out.host_fin: the terminal info of a bin that just finished, one 32-byte record in mapped host memory (two 16-byte
+// stores; only finishing lanes get here).
+__device__ __forceinline__ void host_fin_store(bpp_finished *dst, double ret, double ratio, int len, int boxes) {
+    bpp_finished v;
+    v.ep_ret = ret, v.ratio = ratio, v.ep_len = len, v.counter = boxes, v.reserved[0] = 0, v.reserved[1] = 0;
+    *(bpp_finished *)__builtin_assume_aligned(dst, 32) = v;
 }
 // Episode statistics (main.py:159-162): every bin owns one row [return sum, final-ratio sum, length sum, episodes] of
 // bpp_batch.ep_acc and the lane that decides the bin adds a finished episode to it with a plain read-modify-write.
@@ -469,6 +477,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             if (p.host_reward) {
                 p.host_reward[e] = (float)rew;
                 p.host_done[e] = (ok || noop) ? 0 : 1;
+                if (p.host_fin && !ok && !noop) host_fin_store(p.host_fin + e, st.ep_ret, (double)st.vol_sum / p.binvol, st.ep_len, st.n_boxes);
             }
             p.counter[e] = st.n_boxes;    // bin3D.py:111,124
             p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
@@ -1036,6 +1045,7 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 if (p.host_reward) {
                     p.host_reward[e] = (float)rew;
                     p.host_done[e] = (ok || noop) ? 0 : 1;
+                    if (p.host_fin && !ok && !noop) host_fin_store(p.host_fin + e, st.ep_ret, ratio, st.ep_len, st.n_boxes);
                 }
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
                 p.ratio[e] = ratio;
@@ -2273,6 +2283,8 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
         return fail(BPP_E_BADARG, "bpp_step_out: NULL pointer");
     if ((out->host_reward == nullptr) != (out->host_done == nullptr))
         return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
+    if (out->host_fin != nullptr && (out->host_reward == nullptr || ((uintptr_t)out->host_fin & 31u)))
+        return fail(BPP_E_BADARG, "bpp_step_out: host_fin needs host_reward / host_done and 32-byte alignment");
     if (((uintptr_t)b->hmap & 3u) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
         ((uintptr_t)b->seq_pool & 3u))
         return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
@@ -2311,6 +2323,7 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.done = out->done;
     p.host_reward = out->host_reward;
     p.host_done = out->host_done;
+    p.host_fin = out->host_fin;
     p.counter = out->counter;
     p.ratio = out->ratio;
     p.ep_ret = out->ep_ret;

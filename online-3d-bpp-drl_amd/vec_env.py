@@ -124,12 +124,13 @@ class LazyInfos(object):
     (fresh_outputs=False) they are overwritten by the next step, and a late first access raises instead of returning
     another step's numbers."""
 
-    def __init__(self, env, res, t_now, done=None, serial=None):
+    def __init__(self, env, res, t_now, done=None, serial=None, fin_host=None):
         self._env = env
         self._res = res
         self._t = t_now
         self._done = None if done is None else np.asarray(done).astype(bool)
         self._serial = serial
+        self._fin_host = fin_host      # structured view [E] of this step's bpp_finished records in page-locked memory (written by the step kernel itself)
         self._fin = None       # (bins, [ep_ret, ratio], [ep_len, counter]) of the finished bins
         self._live = None      # (counter, ratio) arrays of all bins
         self._dicts = None
@@ -148,6 +149,14 @@ class LazyInfos(object):
 
     def _finished(self):
         if self._fin is None:
+            if self._fin_host is not None:
+                # the step kernel wrote the finished bins' records into this step's own page-locked buffer (bpp_step_out.host_fin):
+                # no launch, no copy, no synchronisation -- one index scan of `done` and one gather of 32-byte records
+                idx = np.flatnonzero(self._done_mask())
+                rec = self._fin_host[idx]          # (a copy: the staging buffer may go back into use once this object lets go of it)
+                self._fin = (idx, (rec["ep_ret"], rec["ratio"]), (rec["ep_len"], rec["counter"]))
+                self._fin_host = None
+                return self._fin
             self._check_fresh()
             r = self._res
             env = self._env
@@ -503,7 +512,7 @@ class BppVecEnv(object):
         and done into its rollout storage at once, so two or three buffers circulate."""
         import sys
         pool = getattr(self, "_stage_pool", None)
-        n = self._layout()[0]["_small"][3]
+        n = self._stage_bytes()
         if pool is None or (pool and pool[0][1].size != n):
             pool = self._stage_pool = []
         for k, (t, a) in enumerate(pool):
@@ -521,6 +530,17 @@ class BppVecEnv(object):
         a = t.numpy()
         pool.append((t, a))
         return a
+
+    FIN_DTYPE = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("reserved", "<i4", (2,))])
+
+    def _fin_offset(self):
+        """Byte offset of the bpp_finished records inside a staging buffer: behind the per-bin scalar block, 32-byte aligned."""
+        return (self._layout()[0]["_small"][3] + 31) // 32 * 32
+
+    def _stage_bytes(self):
+        """A staging buffer = the per-bin scalar block (29 B per bin; the kernel mirrors its first 5: reward, done) + one
+        32-byte bpp_finished record per bin (bpp_step_out.host_fin: written for the bins that finish, read by `infos`)."""
+        return self._fin_offset() + _lib.FINISHED_BYTES * self.E
 
     def _gather_finished(self, res, n):
         """(bins int32 [n], ep_ret f64 [n], ratio f64 [n], ep_len int32 [n], counter int32 [n]) of the `n` finished bins of
@@ -550,7 +570,7 @@ class BppVecEnv(object):
     @staticmethod
     def _plain(out):
         """Clear the per-call fields of a bpp_step_out (step_tensors sets them in place): no fused draw, no host mirrors."""
-        out.next_action = out.host_reward = out.host_done = None
+        out.next_action = out.host_reward = out.host_done = out.host_fin = None
         return out
 
     def _stream_ptr(self):
@@ -639,8 +659,9 @@ class BppVecEnv(object):
         if _host is not None:
             offs, base = self._layout()[2], _host.ctypes.data
             out.host_reward, out.host_done = base + offs["reward"], base + offs["done"]
+            out.host_fin = base + self._fin_offset()        # (page-locked allocations are page-aligned: the records are 32-byte aligned)
         else:
-            out.host_reward = out.host_done = None
+            out.host_reward = out.host_done = out.host_fin = None
         self._last_stream = sp = self._stream_ptr()
         rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
         if rc:
@@ -721,6 +742,7 @@ class BppVecEnv(object):
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
         (r, host, stream), self._pending = self._pending, None
+        fin_host = None
         if host is None:
             rew, done = r.host_reward_done(stream)          # one 5-byte-per-bin copy + stream synchronise
             done = done.view(np.bool_)
@@ -731,9 +753,11 @@ class BppVecEnv(object):
             offs, E = self._layout()[2], self.E
             rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
             done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
+            fo = self._fin_offset()
+            fin_host = host[fo:fo + _lib.FINISHED_BYTES * E].view(self.FIN_DTYPE)     # valid where done is set (the kernel wrote those)
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         t_now = time.time()
-        infos = LazyInfos(self, r, t_now, done=done, serial=self._serial)
+        infos = LazyInfos(self, r, t_now, done=done, serial=self._serial, fin_host=fin_host)
         if self.monitor is not None and done.any():         # bench/monitor.py:58-72: a row per finished episode
             self.monitor.write(infos.episodes(), t_now)
         return r.obs, reward, done, infos

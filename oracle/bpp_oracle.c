@@ -257,6 +257,8 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         return fail(BPP_E_BADARG, "bpp_step: NULL pointer");
     if ((out->host_reward == NULL) != (out->host_done == NULL))
         return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
+    if (out->host_fin != NULL && (out->host_reward == NULL || ((uintptr_t)out->host_fin & 31u)))
+        return fail(BPP_E_BADARG, "bpp_step_out: host_fin needs host_reward / host_done and 32-byte alignment");
     const int W = b->W, L = b->L, H = b->H, A = W * L;
     for (int e = 0; e < b->num_envs; ++e) {
         bpp_env_state *s = b->state + e;
@@ -330,6 +332,11 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
         out->done[e] = (uint8_t)done;
         if (out->host_reward) out->host_reward[e] = (float)reward, out->host_done[e] = (uint8_t)done;
+        if (out->host_reward && out->host_fin && done) {    /* terminal info of a finished bin; no other record is touched */
+            bpp_finished *f = out->host_fin + e;
+            f->ep_ret = s->ep_ret, f->ratio = out->ratio[e], f->ep_len = s->ep_len, f->counter = s->n_boxes;
+            f->reserved[0] = f->reserved[1] = 0;
+        }
         if (done && b->ep_acc) {                        /* main.py:159-162: the bin's own accumulator row */
             double *a = b->ep_acc + 4 * (size_t)e;
             a[0] += s->ep_ret;

@@ -279,19 +279,41 @@ def test_emulated_step_mirrors_reward_and_done_into_host_buffers(emu, oracle, va
         _, mask = env.reset()
         hr, hd = np.full(E, -1.0, np.float32), np.full(E, 7, np.uint8)
         env._o.host_reward, env._o.host_done = hr.ctypes.data, hd.ctypes.data
+        # bpp_step_out.host_fin (ABI v14): the terminal info of the bins that finish, 32-byte records; no other record is touched
+        fin_dt = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("reserved", "<i4", (2,))])
+        raw = np.zeros(32 * E + 32, np.uint8)
+        off = (-raw.ctypes.data) % 32
+        fin = raw[off:off + 32 * E].view(fin_dt)
+        env._o.host_fin = fin.ctypes.data
         rng = np.random.RandomState(2)
+        finished = 0
         for t in range(12):
             a = oracle.sample_feasible(mask, 4, t)
             a[rng.rand(E) < 0.2] = -1
             a[rng.rand(E) < 0.2] = -2 ** 63                  # BPP_ACTION_NOOP
+            fin["ep_ret"], fin["ratio"], fin["ep_len"], fin["counter"], fin["reserved"] = -5.0, -6.0, -7, -8, -9
             o = env.step(a)
             np.testing.assert_array_equal(hr, o["reward"])
             np.testing.assert_array_equal(hd, o["done"])
+            d = o["done"].astype(bool)
+            for k in ("ep_ret", "ratio", "ep_len", "counter"):
+                np.testing.assert_array_equal(fin[k][d], o[k][d], err_msg=k)
+                assert (fin[k][~d] < 0).all(), k             # running bins: untouched
+            assert (fin["reserved"][d] == 0).all()
+            finished += int(d.sum())
             mask = o["mask"]
+        assert finished > E // 2
+        env._o.host_fin = fin.ctypes.data + 8                # misaligned: refused
+        with pytest.raises(RuntimeError):
+            env.step(a)
+        env._o.host_fin = fin.ctypes.data
         env._o.host_done = None                              # one without the other is refused
         with pytest.raises(RuntimeError):
             env.step(a)
-        env._o.host_reward = None
+        env._o.host_reward = None                            # ... and the records need the mirrors
+        with pytest.raises(RuntimeError):
+            env.step(a)
+        env._o.host_fin = None
         env.step(a)
 
 

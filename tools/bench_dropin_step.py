@@ -35,6 +35,9 @@ def main():
         a = env.sample_feasible(seed=1, step=0)
         host = {"async": 0.0, "wait": 0.0, "n": 0}
 
+        from collections import deque
+        episode_rewards, episode_ratio = deque(maxlen=10), deque(maxlen=10)     # main.py:110-111
+
         def run(kind, n, t0):
             nonlocal a
             for t in range(t0, t0 + n):
@@ -66,10 +69,14 @@ def main():
                 elif kind == "step+episodes_arrays":
                     ep = infos.episodes()
                     ep["r"].sum(), ep["ratio"].sum()
+                elif kind == "step+scan_episodes_arrays_like_main_py":
+                    ep = infos.episodes()                               # main.py:159-162 on the arrays: two deque extends per step
+                    episode_rewards.extend(ep["r"].tolist())
+                    episode_ratio.extend(ep["ratio"].tolist())
                 elif kind == "step+running_info":
                     infos[0]["ratio"]
 
-        kinds = ["tensors", "step", "step+sampler_launch", "step+one_finished_info", "step+episodes_arrays", "step+running_info",
+        kinds = ["tensors", "step", "step+sampler_launch", "step+one_finished_info", "step+episodes_arrays", "step+scan_episodes_arrays_like_main_py", "step+running_info",
                  "step+scan_finished_like_main_py"]
         for kind in kinds:
             n = args.steps if kind != "step+scan_finished_like_main_py" else max(10, args.steps // 10)
@@ -89,8 +96,10 @@ def main():
         torch.cuda.empty_cache()
     out["note"] = ("tensors / step: ONE launch per lock-step (the step kernel draws the next action itself); step = step kernel (also "
                    "writing reward + done, 5 bytes per bin, into page-locked host memory) + stream sync; +sampler_launch: a separate "
-                   "bpp_sample_feasible launch per step as in round 3; +one_finished_info / +episodes_arrays: bpp_gather_finished "
-                   "(one launch + sync) for the finished bins' (r, l, ratio, counter); +scan_finished_like_main_py: a Python loop "
+                   "bpp_sample_feasible launch per step as in round 3; +one_finished_info / +episodes_arrays: the finished bins' (r, l, ratio, "
+                   "counter) from the 32-byte records the step kernel itself left in the step's page-locked buffer (bpp_step_out.host_fin: "
+                   "no launch, no copy, no second sync -- one flatnonzero of `done` + one gather; round 4: bpp_gather_finished, + 82 us); "
+                   "+scan_episodes_arrays_like_main_py: main.py:159-162 on those arrays (two deque extends per step); +scan_finished_like_main_py: a Python loop "
                    "over the ~11 % of bins that finished, two dict reads each; +running_info: counter / ratio of all bins (12 B per bin)")
     print(json.dumps(out))
 
