@@ -191,16 +191,6 @@ int bpp_stream_init(const bpp_stream *s, void *stream);
 /* Generate until gen_next[e] == state[e].episode + depth for every bin (state must be initialised or zero). */
 int bpp_stream_refill(const bpp_stream *s, void *stream);
 
-/* What a finished episode leaves in bpp_step_out.host_fin[e]: the values of the bin's terminal `info`
- * (baselines/bench/monitor.py:58-66, envs/bpp0/bin3D.py:111).  32 bytes = one PCIe write of a 32-byte-aligned record. */
-typedef struct bpp_finished {
-    double  ep_ret;    /* info['episode']['r'] before round(., 6)  */
-    double  ratio;     /* info['ratio']                            */
-    int32_t ep_len;    /* info['episode']['l']                     */
-    int32_t counter;   /* info['counter']                          */
-    int32_t reserved[2];
-} bpp_finished;
-
 /* Outputs of one lock-step.  Layout = what VecPyTorch hands the ACKTR loop (acktr/envs.py:170-193)
  * plus the location mask the loop builds per observation (main.py:122-129,163-169). */
 typedef struct bpp_step_out {
@@ -225,11 +215,6 @@ typedef struct bpp_step_out {
     uint8_t *host_done;   /* memory): bpp_step ALSO writes reward / done there, so that the host side of VecEnv.step_wait()   */
                           /* (acktr/envs.py:189-193: CPU reward tensor, numpy done) needs no copy, only bpp_wait(stream).     */
                           /* Both or neither.                                                                                  */
-    struct bpp_finished *host_fin; /* NULL, or (only together with host_reward / host_done) [E] records in the same kind of mapped
-                          host memory: bpp_step ALSO writes the record of every bin that FINISHED an episode in this lock-step --
-                          and touches no other bin's -- so that `infos` of the finished bins (main.py:159-162 reads
-                          infos[i]['episode']['r'] and infos[i]['ratio'] of exactly those) need no launch, no copy and no second
-                          synchronisation: the host indexes host_fin with the bins whose host_done is set.                    */
 } bpp_step_out;
 
 /* Launch-shape tuning knobs of the step/reset/mask kernels (no reference counterpart).  Process-global;
@@ -385,6 +370,12 @@ int bpp_wait(void *stream);
  * is needed crosses PCIe, in one transfer, already laid out as the arrays a caller wants.  dev == NULL: `host` is
  * page-locked memory MAPPED into the device and the kernel writes header and arrays there itself (no staging copy).  count != n (the caller's `done`
  * belongs to another step): BPP_E_BADARG.  Blocks the calling thread like bpp_fetch_to_host. */
+/* n == BPP_GATHER_ENQUEUE_ONLY (dev must be NULL, `host` mapped page-locked memory of BPP_FINISHED_BYTES(E) bytes): the EAGER form
+ * -- the compaction is only enqueued behind the step, with the five arrays laid out for E entries (ep_ret at 32, ratio at 32 + 8 E,
+ * ep_len at 32 + 16 E, counter at 32 + 20 E, bin at 32 + 24 E); nothing is copied, nothing waited for, nothing checked: the caller's
+ * own synchronisation of the step (bpp_wait) covers it, the header's count then says how many entries each array holds.  One more
+ * launch per step (~10 us of device time at 65 536 bins) instead of a launch AND a second synchronisation when `infos` is read. */
+#define BPP_GATHER_ENQUEUE_ONLY (-1)
 #define BPP_FINISHED_BYTES(n) (32 + 28 * (int64_t)(n) + 4)      /* (+ 4: room for the 8-byte alignment of nothing -- n may be odd) */
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream);

@@ -120,7 +120,6 @@ struct Params {
     uint8_t *done;
     float *host_reward;   // mirrors of reward / done in mapped host memory, or nullptr
     uint8_t *host_done;
-    bpp_finished *host_fin;   // records of the bins that finish an episode, in mapped host memory, or nullptr
     int32_t *counter;
     double *ratio;
     double *ep_ret;
@@ -131,6 +130,13 @@ struct Params {
     int64_t env_id_base;
 };
 
+// Measured on gfx950 this round (profiles/r5e_ubench_sparse_exec_by_instruction.jsonl, tools/ubench sparse): a vector instruction of
+// the 4-cycle class (shifts, multiplies, min / max, compares, selects, conversions, three-operand adds, v_readlane ... -- everything
+// but v_add / v_sub / v_and / v_xor / v_mov, which issue in ~2.5 cycles) takes ~22 cycles instead of ~4 in a stream of such
+// instructions when 8 or fewer of the wave's 64 lanes are active.  Rewriting the kernel's narrow sections (slot words, item read,
+// fill offsets, draw decode, statistics sums by all lanes of the bin; candidates spread evenly over the passes) did NOT move
+// the kernels (profiles/r5g_*: 28.5 -> 28.6 us, 35.1 -> 35.4 us, 54.1 -> 53.9 us): those sections are short and sit between
+// barriers and LDS round trips where the vector pipe is not the limiter.  Kept out of the source; the measurement stays.
 // ---- bpp_batch.seq_cache: the row cache of a ring pool ---------------------------------------------------------------
 // A read that misses every cache takes 15-18 us under the step kernel's write stream -- longer than a step workgroup
 // lives -- so ONE lane waiting for a ring row keeps its workgroup resident past its natural end and the launch pays 6 us
@@ -246,13 +252,6 @@ __device__ __forceinline__ LookAheadAt look_ahead_at(const Params &p, int seq, i
     a.f1 = (size_t)(ring ? seq : seq_n) * T + (ring ? 0 : min(1, T - 1));
     a.f2 = (size_t)(ring ? seq : seq_nn) * T + (ring ? 1 : 0);
     return a;
-}
-// bpp_step_out.host_fin: the terminal info of a bin that just finished, one 32-byte record in mapped host memory (two 16-byte
-// stores; only finishing lanes get here).
-__device__ __forceinline__ void host_fin_store(bpp_finished *dst, double ret, double ratio, int len, int boxes) {
-    bpp_finished v;
-    v.ep_ret = ret, v.ratio = ratio, v.ep_len = len, v.counter = boxes, v.reserved[0] = 0, v.reserved[1] = 0;
-    *(bpp_finished *)__builtin_assume_aligned(dst, 32) = v;
 }
 // Episode statistics (main.py:159-162): every bin owns one row [return sum, final-ratio sum, length sum, episodes] of
 // bpp_batch.ep_acc and the lane that decides the bin adds a finished episode to it with a plain read-modify-write.
@@ -477,7 +476,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Param
             if (p.host_reward) {
                 p.host_reward[e] = (float)rew;
                 p.host_done[e] = (ok || noop) ? 0 : 1;
-                if (p.host_fin && !ok && !noop) host_fin_store(p.host_fin + e, st.ep_ret, (double)st.vol_sum / p.binvol, st.ep_len, st.n_boxes);
             }
             p.counter[e] = st.n_boxes;    // bin3D.py:111,124
             p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
@@ -1045,7 +1043,6 @@ __global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel
                 if (p.host_reward) {
                     p.host_reward[e] = (float)rew;
                     p.host_done[e] = (ok || noop) ? 0 : 1;
-                    if (p.host_fin && !ok && !noop) host_fin_store(p.host_fin + e, st.ep_ret, ratio, st.ep_len, st.n_boxes);
                 }
                 p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
                 p.ratio[e] = ratio;
@@ -1965,25 +1962,54 @@ __global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, in
     if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next (stream-ordered) call
 }
 
-// bpp_gather_finished: ordered compaction of the finished bins' per-bin outputs by ONE workgroup (64 KB of `done` per
-// 65 536 bins -- a few microseconds; the transfer to the host is what the call is about).  Thread t of a round owns 16
-// consecutive bins; exclusive prefix of the per-thread counts by wave shuffles + one LDS pass over the 16 waves.  Output:
-// header + five arrays of n entries (include/bpp_abi.h); entries beyond n (a caller whose count is wrong) are dropped,
-// the header tells.
-__global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
-                                                                const int32_t *ep_len, const int32_t *counter, int E,
-                                                                unsigned char *out, int n) {
-    static __shared__ int wave_tot[16];
-    static __shared__ int wave_off[16];
+// bpp_gather_finished: ordered compaction of the finished bins' per-bin outputs.  Workgroup w owns the bins [w * chunk, (w + 1) *
+// chunk) (chunk a multiple of 4 096; at most 64 workgroups) and needs no word from the others: it counts the finished bins in
+// front of its chunk itself (the `done` bytes before it: at most 64 KB per 65 536 bins, 16 bytes per load, resident in L2), then
+// compacts its own bins in rounds of 4 096 -- thread t of a round owns 16 consecutive bins; exclusive prefix of the per-thread
+// counts by wave shuffles + one LDS pass over the 4 waves.  One launch, no scratch, no hand-off between workgroups, output in
+// ascending bin order whatever the order the workgroups run in.  (Round 4 ran ONE workgroup of 1 024 threads over all bins: four
+// serial rounds of gathers at 65 536 bins, ~60 us on the device.)  Output: header + five arrays of n entries (include/bpp_abi.h);
+// entries beyond n (a caller whose count is wrong) are dropped, the header tells.
+constexpr int kGatherThreads = 256, kGatherRound = kGatherThreads * 16, kGatherMaxGroups = 64;
+__device__ __forceinline__ int nonzero_bytes(uint32_t v) {
+    const uint32_t t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v;    // bit 7 of every byte that is not zero
+    return __popc(t & 0x80808080u);
+}
+__global__ __launch_bounds__(kGatherThreads) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
+                                                                          const int32_t *ep_len, const int32_t *counter, int E,
+                                                                          unsigned char *out, int n, int chunk) {
+    constexpr int NW = kGatherThreads / 64;
+    static __shared__ int wave_tot[NW];
+    static __shared__ int wave_off[NW];
     static __shared__ int total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
     int32_t *o_len = (int32_t *)(o_ratio + n), *o_cnt = o_len + n, *o_bin = o_cnt + n;
+    const int c_lo = (int)blockIdx.x * chunk, c_hi = min(E, c_lo + chunk);
+    const bool aligned = (((uintptr_t)done) & 15u) == 0;
+    // ---- finished bins in front of this workgroup's chunk (c_lo is a multiple of 4 096)
+    int before = 0;
+    if (aligned) {
+        for (int i = t; i < c_lo / 16; i += kGatherThreads) {
+            const uint4 v = ((const uint4 *)done)[i];
+            before += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+        }
+    } else {
+        for (int i = t; i < c_lo; i += kGatherThreads) before += done[i] != 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    if (lane == 0) wave_tot[wave] = before;
+    __syncthreads();
     int base = 0;
-    for (int c0 = 0; c0 < E; c0 += 1024 * 16) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) base += wave_tot[k];
+    __syncthreads();
+    // ---- this workgroup's own bins
+    for (int c0 = c_lo; c0 < c_hi; c0 += kGatherRound) {
         const int e0 = c0 + t * 16;
         uint32_t m = 0;
-        if (e0 + 16 <= E && (((uintptr_t)(done + e0)) & 15u) == 0) {
+        if (e0 + 16 <= c_hi && aligned) {
             const uint4 v = *(const uint4 *)(done + e0);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1992,7 +2018,7 @@ __global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *d
                 for (int k = 0; k < 4; ++k) m |= ((w[q] >> (8 * k)) & 255u) ? 1u << (4 * q + k) : 0u;
         } else {
             for (int k = 0; k < 16; ++k)
-                if (e0 + k < E && done[e0 + k]) m |= 1u << k;
+                if (e0 + k < c_hi && done[e0 + k]) m |= 1u << k;
         }
         const int cnt = __popc(m);
         int incl = cnt;
@@ -2005,7 +2031,7 @@ __global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *d
         __syncthreads();
         if (t == 0) {
             int s = 0;
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < NW; ++k) {
                 wave_off[k] = s;
                 s += wave_tot[k];
             }
@@ -2029,7 +2055,14 @@ __global__ __launch_bounds__(1024) void compact_finished_kernel(const uint8_t *d
         base += total;
         __syncthreads();
     }
-    if (t < 8) ((int32_t *)out)[t] = t == 0 ? base : 0;
+    if (blockIdx.x == gridDim.x - 1 && t < 8) ((int32_t *)out)[t] = t == 0 ? base : 0;   // the last chunk's running count is the total
+}
+// launch shape of the compaction: at most kGatherMaxGroups workgroups, chunks of whole rounds
+static inline void gather_shape(int E, int &groups, int &chunk) {
+    const int rounds = (E + kGatherRound - 1) / kGatherRound;
+    const int want = rounds < kGatherMaxGroups ? rounds : kGatherMaxGroups;
+    chunk = (rounds + want - 1) / want * kGatherRound;
+    groups = (E + chunk - 1) / chunk;
 }
 
 thread_local char g_err[256];
@@ -2283,8 +2316,6 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
         return fail(BPP_E_BADARG, "bpp_step_out: NULL pointer");
     if ((out->host_reward == nullptr) != (out->host_done == nullptr))
         return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
-    if (out->host_fin != nullptr && (out->host_reward == nullptr || ((uintptr_t)out->host_fin & 31u)))
-        return fail(BPP_E_BADARG, "bpp_step_out: host_fin needs host_reward / host_done and 32-byte alignment");
     if (((uintptr_t)b->hmap & 3u) || !aligned16(b->state) || !aligned16(out->obs) || (out->mask && !aligned16(out->mask)) ||
         ((uintptr_t)b->seq_pool & 3u))
         return fail(BPP_E_BADARG, "buffers must be 16-byte aligned");
@@ -2323,7 +2354,6 @@ int fill_batch(Launch &l, const bpp_batch *b, const bpp_step_out *out, bool need
     p.done = out->done;
     p.host_reward = out->host_reward;
     p.host_done = out->host_done;
-    p.host_fin = out->host_fin;
     p.counter = out->counter;
     p.ratio = out->ratio;
     p.ep_ret = out->ep_ret;
@@ -2666,12 +2696,26 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
     if (!done || !ep_ret || !ratio || !ep_len || !counter || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
-    if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    if (E <= 0 || n < BPP_GATHER_ENQUEUE_ONLY || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    if (n == BPP_GATHER_ENQUEUE_ONLY) {
+        // the eager form: the compaction is only ENQUEUED behind the step (arrays laid out for E entries, straight into mapped host
+        // memory); the caller's one synchronisation of the step covers it and the header then tells how many entries there are
+        if (dev) return fail(BPP_E_BADARG, "bpp_gather_finished: BPP_GATHER_ENQUEUE_ONLY writes into mapped host memory (dev must be NULL)");
+        if ((uintptr_t)host & 7u) return fail(BPP_E_BADARG, "bpp_gather_finished: buffers must be 8-byte aligned");
+        int groups0, chunk0;
+        gather_shape(E, groups0, chunk0);
+        hipLaunchKernelGGL(compact_finished_kernel, dim3(groups0), dim3(kGatherThreads), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
+                           (unsigned char *)host, E, chunk0);
+        hipError_t e0 = hipGetLastError();
+        return e0 == hipSuccess ? 0 : hip_fail(e0, "kernel launch");
+    }
     if (((uintptr_t)dev & 7u) || ((uintptr_t)host & 7u)) return fail(BPP_E_BADARG, "bpp_gather_finished: buffers must be 8-byte aligned");
     // dev == NULL: `host` is page-locked memory mapped into the device and the kernel writes the arrays there itself
     // (~200 KB of mostly consecutive stores at 65 536 bins) -- no staging buffer, no copy engine
-    hipLaunchKernelGGL(compact_finished_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
-                       (unsigned char *)(dev ? dev : host), n);
+    int groups, chunk;
+    gather_shape(E, groups, chunk);
+    hipLaunchKernelGGL(compact_finished_kernel, dim3(groups), dim3(kGatherThreads), 0, (hipStream_t)stream, done, ep_ret, ratio, ep_len, counter, E,
+                       (unsigned char *)(dev ? dev : host), n, chunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     if (dev) {

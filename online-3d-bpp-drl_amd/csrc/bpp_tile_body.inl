@@ -363,7 +363,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
         if (p.host_reward) {        // mirrors in mapped host memory: step_wait() then only waits for the stream
             p.host_reward[e] = out_rew;
             p.host_done[e] = out_ok ? 0 : 1;
-            if (p.host_fin && fin) host_fin_store(p.host_fin + e, fin_ret, fin_ratio, fin_len, out_boxes);   // infos of the finished bins
         }
         p.counter[e] = out_boxes;
         p.ratio[e] = fin_ratio;

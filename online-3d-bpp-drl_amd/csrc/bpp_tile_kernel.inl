@@ -184,9 +184,12 @@ __device__ __forceinline__ void store_out4_nt(float4 *dst, float a, float b, flo
 }
 
 // The kernel itself, in its two forms (bpp_tile_body.inl).
+// amdgpu_num_sgpr(80): a CU admits eight 256-thread workgroups only up to 80 scalar registers (bpp_kernels.hip: resource
+// cliffs).  The kernels of the BASELINE configs sit at 77-80 by themselves; the 20x20 + rotation step kernel compiled to 84
+// (seven workgroups per CU) -- with the cap the compiler parks a few launch constants in vector-register lanes instead.
 #define BPP_TILE_NAME bpp_tile_kernel
 #define BPP_TILE_CACHE false
-#define BPP_TILE_ATTR
+#define BPP_TILE_ATTR __attribute__((amdgpu_num_sgpr(80)))
 #include "bpp_tile_body.inl"
 #undef BPP_TILE_NAME
 #undef BPP_TILE_CACHE

@@ -45,6 +45,7 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
         pool = make_pool(size, getattr(args, "data_type", getattr(args, "item_seq", "cut2")),
                          getattr(args, "box_size_set", None), rot, seed=int(seed), pool_size=pool_size)
     env_kwargs.setdefault("fresh_outputs", True)   # reference semantics: earlier results stay valid
+    env_kwargs.setdefault("eager_infos", True)     # the reference loop reads the finished episodes' infos every step (main.py:159-162)
     env = BppVecEnv(int(num_processes), size, enable_rotation=rot, pool=pool, device=device, **env_kwargs)
     env.venv = _vec_normalize_holder()
     if log_dir is not None:     # acktr/envs.py:54-58

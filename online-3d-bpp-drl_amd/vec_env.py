@@ -124,14 +124,13 @@ class LazyInfos(object):
     (fresh_outputs=False) they are overwritten by the next step, and a late first access raises instead of returning
     another step's numbers."""
 
-    def __init__(self, env, res, t_now, done=None, serial=None, fin_host=None):
+    def __init__(self, env, res, t_now, done=None, serial=None, fin=None):
         self._env = env
         self._res = res
         self._t = t_now
         self._done = None if done is None else np.asarray(done).astype(bool)
         self._serial = serial
-        self._fin_host = fin_host      # structured view [E] of this step's bpp_finished records in page-locked memory (written by the step kernel itself)
-        self._fin = None       # (bins, [ep_ret, ratio], [ep_len, counter]) of the finished bins
+        self._fin = fin        # (bins, [ep_ret, ratio], [ep_len, counter]) of the finished bins; handed in by an env with eager_infos
         self._live = None      # (counter, ratio) arrays of all bins
         self._dicts = None
 
@@ -149,14 +148,6 @@ class LazyInfos(object):
 
     def _finished(self):
         if self._fin is None:
-            if self._fin_host is not None:
-                # the step kernel wrote the finished bins' records into this step's own page-locked buffer (bpp_step_out.host_fin):
-                # no launch, no copy, no synchronisation -- one index scan of `done` and one gather of 32-byte records
-                idx = np.flatnonzero(self._done_mask())
-                rec = self._fin_host[idx]          # (a copy: the staging buffer may go back into use once this object lets go of it)
-                self._fin = (idx, (rec["ep_ret"], rec["ratio"]), (rec["ep_len"], rec["counter"]))
-                self._fin_host = None
-                return self._fin
             self._check_fresh()
             r = self._res
             env = self._env
@@ -295,6 +286,10 @@ class BppVecEnv(object):
     mask_rule:      'utils' (acktr/utils.py check_box -- what the training loop consumes) or 'space'
                     (Space.check_box, i.e. PackingGame.get_possible_position).
     compute_mask:   also produce the feasibility mask of every returned observation (`location_masks`).
+    eager_infos:    step() also enqueues the compaction of the finished bins' infos behind the step kernel (one more launch,
+                    ~10 us of device time at 65 536 bins), so that reading `infos.episodes()` / a finished bin's dict costs no
+                    launch and no second synchronisation -- for loops that look at the finished episodes EVERY step, as
+                    main.py:159-162 does (make_vec_envs sets it); False: the gather happens when somebody looks.
     fresh_outputs:  allocate new output tensors every step (reference semantics: results of earlier
                     steps stay valid); False = reuse one set of buffers, results are valid until the
                     next step/reset call.
@@ -312,7 +307,7 @@ class BppVecEnv(object):
     """
 
     def __init__(self, num_envs, container_size=(10, 10, 10), enable_rotation=False, pool=None, device="cuda",
-                 env_id_base=0, env_id_total=None, mask_rule="utils", compute_mask=True, fresh_outputs=False, stream=None):
+                 env_id_base=0, env_id_total=None, mask_rule="utils", compute_mask=True, fresh_outputs=False, stream=None, eager_infos=False):
         if not torch.cuda.is_available():
             raise RuntimeError("BppVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -341,6 +336,7 @@ class BppVecEnv(object):
         self.mask_rule = {"utils": _lib.RULE_UTILS, "space": _lib.RULE_SPACE}[mask_rule]
         self.compute_mask = bool(compute_mask)
         self.fresh_outputs = bool(fresh_outputs)
+        self.eager_infos = bool(eager_infos)
         self.env_id_base = int(env_id_base)
         self.env_id_total = int(env_id_total) if env_id_total is not None else self.env_id_base + self.E
         dev = self.device
@@ -531,16 +527,15 @@ class BppVecEnv(object):
         pool.append((t, a))
         return a
 
-    FIN_DTYPE = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("reserved", "<i4", (2,))])
-
     def _fin_offset(self):
-        """Byte offset of the bpp_finished records inside a staging buffer: behind the per-bin scalar block, 32-byte aligned."""
-        return (self._layout()[0]["_small"][3] + 31) // 32 * 32
+        """Byte offset of the eager gather's area (bpp_gather_finished, BPP_GATHER_ENQUEUE_ONLY: 32-byte header + five arrays laid
+        out for E entries) inside a staging buffer: behind the per-bin scalar block, 8-byte aligned."""
+        return (self._layout()[0]["_small"][3] + 7) // 8 * 8
 
     def _stage_bytes(self):
-        """A staging buffer = the per-bin scalar block (29 B per bin; the kernel mirrors its first 5: reward, done) + one
-        32-byte bpp_finished record per bin (bpp_step_out.host_fin: written for the bins that finish, read by `infos`)."""
-        return self._fin_offset() + _lib.FINISHED_BYTES * self.E
+        """A staging buffer = the per-bin scalar block (29 B per bin; the kernel mirrors its first 5: reward, done) and, with
+        eager_infos, the compacted records of the finished bins (28 B per bin of room; a step fills the first ~11 % of each array)."""
+        return self._fin_offset() + ((32 + 28 * self.E + 4 + 7) // 8 * 8 if self.eager_infos else 0)
 
     def _gather_finished(self, res, n):
         """(bins int32 [n], ep_ret f64 [n], ratio f64 [n], ep_len int32 [n], counter int32 [n]) of the `n` finished bins of
@@ -570,7 +565,7 @@ class BppVecEnv(object):
     @staticmethod
     def _plain(out):
         """Clear the per-call fields of a bpp_step_out (step_tensors sets them in place): no fused draw, no host mirrors."""
-        out.next_action = out.host_reward = out.host_done = out.host_fin = None
+        out.next_action = out.host_reward = out.host_done = None
         return out
 
     def _stream_ptr(self):
@@ -659,9 +654,8 @@ class BppVecEnv(object):
         if _host is not None:
             offs, base = self._layout()[2], _host.ctypes.data
             out.host_reward, out.host_done = base + offs["reward"], base + offs["done"]
-            out.host_fin = base + self._fin_offset()        # (page-locked allocations are page-aligned: the records are 32-byte aligned)
         else:
-            out.host_reward = out.host_done = out.host_fin = None
+            out.host_reward = out.host_done = None
         self._last_stream = sp = self._stream_ptr()
         rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
         if rc:
@@ -735,6 +729,14 @@ class BppVecEnv(object):
         sample=(seed, step, out): as in step_tensors -- also draw a uniform-feasible action for the new observation."""
         host = self._staging(mapped=True)      # None: every page-locked buffer is still referenced -> step_wait() copies
         res = self.step_tensors(actions, sample=sample, _host=host)
+        if self.eager_infos and host is not None:
+            # the finished bins' (r, ratio, l, counter, bin), compacted in bin order straight into this step's page-locked buffer by
+            # one more launch behind the step kernel: step_wait()'s ONE synchronisation covers it (bpp_gather_finished, eager form)
+            base, lay = res._flat.data_ptr(), res._layout
+            rc = self.lib.bpp_gather_finished(base + lay["done"][0], base + lay["ep_ret"][0], base + lay["ratio"][0], base + lay["ep_len"][0],
+                                              base + lay["counter"][0], self.E, None, host.ctypes.data + self._fin_offset(), -1, self._last_stream)
+            if rc:
+                _lib.check(rc)
         self._pending = (res, host, self._last_stream)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
 
     def step_wait(self):
@@ -742,7 +744,7 @@ class BppVecEnv(object):
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
         (r, host, stream), self._pending = self._pending, None
-        fin_host = None
+        fin = None
         if host is None:
             rew, done = r.host_reward_done(stream)          # one 5-byte-per-bin copy + stream synchronise
             done = done.view(np.bool_)
@@ -753,11 +755,15 @@ class BppVecEnv(object):
             offs, E = self._layout()[2], self.E
             rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
             done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
-            fo = self._fin_offset()
-            fin_host = host[fo:fo + _lib.FINISHED_BYTES * E].view(self.FIN_DTYPE)     # valid where done is set (the kernel wrote those)
+            if self.eager_infos:        # the gather enqueued by step_async is complete too: slice the five arrays (copies: ~28 B per finished bin)
+                fo, E8 = self._fin_offset() + 32, 8 * E
+                n = int(host[fo - 32:fo - 28].view("<i4")[0])
+                fin = (host[fo + 3 * E8:fo + 3 * E8 + 4 * n].view("<i4").copy(),
+                       (host[fo:fo + 8 * n].view("<f8").copy(), host[fo + E8:fo + E8 + 8 * n].view("<f8").copy()),
+                       (host[fo + 2 * E8:fo + 2 * E8 + 4 * n].view("<i4").copy(), host[fo + 2 * E8 + 4 * E:fo + 2 * E8 + 4 * E + 4 * n].view("<i4").copy()))
         reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         t_now = time.time()
-        infos = LazyInfos(self, r, t_now, done=done, serial=self._serial, fin_host=fin_host)
+        infos = LazyInfos(self, r, t_now, done=done, serial=self._serial, fin=fin)
         if self.monitor is not None and done.any():         # bench/monitor.py:58-72: a row per finished episode
             self.monitor.write(infos.episodes(), t_now)
         return r.obs, reward, done, infos

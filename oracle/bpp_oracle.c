@@ -257,8 +257,6 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         return fail(BPP_E_BADARG, "bpp_step: NULL pointer");
     if ((out->host_reward == NULL) != (out->host_done == NULL))
         return fail(BPP_E_BADARG, "bpp_step_out: host_reward and host_done go together");
-    if (out->host_fin != NULL && (out->host_reward == NULL || ((uintptr_t)out->host_fin & 31u)))
-        return fail(BPP_E_BADARG, "bpp_step_out: host_fin needs host_reward / host_done and 32-byte alignment");
     const int W = b->W, L = b->L, H = b->H, A = W * L;
     for (int e = 0; e < b->num_envs; ++e) {
         bpp_env_state *s = b->state + e;
@@ -332,11 +330,6 @@ int bpp_step(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out
         out->reward[e] = (float)reward;                 /* acktr/envs.py:192 .float() */
         out->done[e] = (uint8_t)done;
         if (out->host_reward) out->host_reward[e] = (float)reward, out->host_done[e] = (uint8_t)done;
-        if (out->host_reward && out->host_fin && done) {    /* terminal info of a finished bin; no other record is touched */
-            bpp_finished *f = out->host_fin + e;
-            f->ep_ret = s->ep_ret, f->ratio = out->ratio[e], f->ep_len = s->ep_len, f->counter = s->n_boxes;
-            f->reserved[0] = f->reserved[1] = 0;
-        }
         if (done && b->ep_acc) {                        /* main.py:159-162: the bin's own accumulator row */
             double *a = b->ep_acc + 4 * (size_t)e;
             a[0] += s->ep_ret;
@@ -483,7 +476,10 @@ int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double 
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream) {
     (void)stream;
     if (!done || !ep_ret || !ratio || !ep_len || !counter || !host) return fail(BPP_E_BADARG, "bpp_gather_finished: NULL pointer");
-    if (E <= 0 || n < 0 || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    if (E <= 0 || n < BPP_GATHER_ENQUEUE_ONLY || n > E) return fail(BPP_E_BADARG, "bpp_gather_finished: bad size");
+    int eager = n == BPP_GATHER_ENQUEUE_ONLY;       /* arrays laid out for E entries, no count check (include/bpp_abi.h) */
+    if (eager && dev) return fail(BPP_E_BADARG, "bpp_gather_finished: BPP_GATHER_ENQUEUE_ONLY writes into mapped host memory (dev must be NULL)");
+    if (eager) n = E;
     if (!dev) dev = host;
     unsigned char *out = (unsigned char *)dev;
     double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
@@ -497,7 +493,7 @@ int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double 
     memset(out, 0, 32);
     *(int32_t *)out = k;
     if (dev != host) memmove(host, dev, (size_t)BPP_FINISHED_BYTES(n));
-    if (k != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
+    if (!eager && k != n) return fail(BPP_E_BADARG, "bpp_gather_finished: n is not the number of finished bins of this step");
     return 0;
 }
 

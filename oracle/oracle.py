@@ -43,8 +43,7 @@ class StepOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("obs", "mask", "reward", "done", "counter", "ratio", "ep_ret", "ep_len",
                                                "next_action")] + [("sample_seed", ctypes.c_uint64),
                                                                   ("sample_step", ctypes.c_uint64),
-                                                                  ("host_reward", ctypes.c_void_p), ("host_done", ctypes.c_void_p),
-                                                                  ("host_fin", ctypes.c_void_p)]
+                                                                  ("host_reward", ctypes.c_void_p), ("host_done", ctypes.c_void_p)]
 
 
 class Knobs(ctypes.Structure):

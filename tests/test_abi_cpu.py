@@ -92,7 +92,8 @@ def test_product_never_imports_the_oracle():
 
 
 def test_bench_touches_the_reference_only_inside_the_cpu_baseline_leg():
-    """bench.py may execute oracle/ and oracle/_ref/ only as the reported CPU baseline; /root/reference never."""
+    """bench.py may execute oracle/_ref/ only as the reported CPU baseline and oracle/ only there and as the CHECKER of its
+    in-run parity gate (parity_gate, outside every timed region); /root/reference never."""
     txt = open(os.path.join(ROOT, "bench.py")).read()
     assert "/root/reference" not in txt.replace("/root/reference is never read", "")
     body = txt[txt.index("def main():"):]

@@ -279,41 +279,19 @@ def test_emulated_step_mirrors_reward_and_done_into_host_buffers(emu, oracle, va
         _, mask = env.reset()
         hr, hd = np.full(E, -1.0, np.float32), np.full(E, 7, np.uint8)
         env._o.host_reward, env._o.host_done = hr.ctypes.data, hd.ctypes.data
-        # bpp_step_out.host_fin (ABI v14): the terminal info of the bins that finish, 32-byte records; no other record is touched
-        fin_dt = np.dtype([("ep_ret", "<f8"), ("ratio", "<f8"), ("ep_len", "<i4"), ("counter", "<i4"), ("reserved", "<i4", (2,))])
-        raw = np.zeros(32 * E + 32, np.uint8)
-        off = (-raw.ctypes.data) % 32
-        fin = raw[off:off + 32 * E].view(fin_dt)
-        env._o.host_fin = fin.ctypes.data
         rng = np.random.RandomState(2)
-        finished = 0
         for t in range(12):
             a = oracle.sample_feasible(mask, 4, t)
             a[rng.rand(E) < 0.2] = -1
             a[rng.rand(E) < 0.2] = -2 ** 63                  # BPP_ACTION_NOOP
-            fin["ep_ret"], fin["ratio"], fin["ep_len"], fin["counter"], fin["reserved"] = -5.0, -6.0, -7, -8, -9
             o = env.step(a)
             np.testing.assert_array_equal(hr, o["reward"])
             np.testing.assert_array_equal(hd, o["done"])
-            d = o["done"].astype(bool)
-            for k in ("ep_ret", "ratio", "ep_len", "counter"):
-                np.testing.assert_array_equal(fin[k][d], o[k][d], err_msg=k)
-                assert (fin[k][~d] < 0).all(), k             # running bins: untouched
-            assert (fin["reserved"][d] == 0).all()
-            finished += int(d.sum())
             mask = o["mask"]
-        assert finished > E // 2
-        env._o.host_fin = fin.ctypes.data + 8                # misaligned: refused
-        with pytest.raises(RuntimeError):
-            env.step(a)
-        env._o.host_fin = fin.ctypes.data
         env._o.host_done = None                              # one without the other is refused
         with pytest.raises(RuntimeError):
             env.step(a)
-        env._o.host_reward = None                            # ... and the records need the mirrors
-        with pytest.raises(RuntimeError):
-            env.step(a)
-        env._o.host_fin = None
+        env._o.host_reward = None
         env.step(a)
 
 
@@ -369,6 +347,20 @@ def test_emulated_gather_finished_compacts_in_bin_order(emu, oracle):
             got[name] = dict(ret=b[:8 * n].view("<f8").copy(), ratio=b[8 * n:16 * n].view("<f8").copy(), ln=b[16 * n:20 * n].view("<i4").copy(),
                              cnt=b[20 * n:24 * n].view("<i4").copy(), bins=b[24 * n:28 * n].view("<i4").copy())
             assert call(n + 1 if n < E else n - 1)[0] != 0          # the caller's `done` is not this step's
+            # the EAGER form (BPP_GATHER_ENQUEUE_ONLY): arrays laid out for E entries straight in `host`, no count to agree with
+            host = np.full(nb // 8, -1.0).view(np.uint8)
+            rc = lib.bpp_gather_finished(ctypes.c_void_p(done.ctypes.data), ctypes.c_void_p(ret.ctypes.data), ctypes.c_void_p(ratio.ctypes.data),
+                                         ctypes.c_void_p(ln.ctypes.data), ctypes.c_void_p(cnt.ctypes.data), ctypes.c_int32(E), None,
+                                         ctypes.c_void_p(host.ctypes.data), ctypes.c_int32(-1), None)
+            assert rc == 0 and host[:4].view("<i4")[0] == n, lib.bpp_last_error()
+            b = host[32:]
+            eager = dict(ret=b[:8 * n].view("<f8"), ratio=b[8 * E:8 * E + 8 * n].view("<f8"), ln=b[16 * E:16 * E + 4 * n].view("<i4"),
+                         cnt=b[20 * E:20 * E + 4 * n].view("<i4"), bins=b[24 * E:24 * E + 4 * n].view("<i4"))
+            for f in eager:
+                np.testing.assert_array_equal(eager[f], got[name][f], err_msg="eager " + f)
+            assert lib.bpp_gather_finished(ctypes.c_void_p(done.ctypes.data), ctypes.c_void_p(ret.ctypes.data), ctypes.c_void_p(ratio.ctypes.data),
+                                           ctypes.c_void_p(ln.ctypes.data), ctypes.c_void_p(cnt.ctypes.data), ctypes.c_int32(E), ctypes.c_void_p(host.ctypes.data),
+                                           ctypes.c_void_p(host.ctypes.data), ctypes.c_int32(-1), None) != 0      # eager + a device staging buffer: refused
         idx = np.flatnonzero(done)
         np.testing.assert_array_equal(got["oracle"]["bins"], idx)
         np.testing.assert_array_equal(got["oracle"]["ret"], ret[idx])

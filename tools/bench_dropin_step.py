@@ -29,8 +29,8 @@ def main():
     size = (10, 10, 10)
     pool = bpp_amd.sequences.cut2_pool(size, 8192, seed=0)
     out = {"envs": args.envs, "steps": args.steps}
-    for fresh in (False, True):
-        env = bpp_amd.BppVecEnv(args.envs, size, pool=pool, fresh_outputs=fresh)
+    for fresh, eager in ((False, False), (False, True), (True, True)):
+        env = bpp_amd.BppVecEnv(args.envs, size, pool=pool, fresh_outputs=fresh, eager_infos=eager)
         env.reset()
         a = env.sample_feasible(seed=1, step=0)
         host = {"async": 0.0, "wait": 0.0, "n": 0}
@@ -61,7 +61,6 @@ def main():
                     if idx.size:
                         infos[int(idx[0])]["episode"]["r"]
                 elif kind == "step+scan_finished_like_main_py":
-                    episode_rewards, episode_ratio = [], []
                     for i in infos.done_indices():                      # main.py:159-162 over the finished bins
                         if "episode" in infos[i].keys():
                             episode_rewards.append(infos[i]["episode"]["r"])
@@ -87,18 +86,19 @@ def main():
             run(kind, n, 30)
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / n * 1e6
-            key = "%s%s_us_per_lockstep" % (kind, "_fresh_outputs" if fresh else "")
+            tag = ("_fresh_outputs" if fresh else "") + ("_eager_infos" if eager else "")
+            key = "%s%s_us_per_lockstep" % (kind, tag)
             out[key] = round(us, 1)
             if kind == "step":
-                out["step%s_host_us_in_step_async" % ("_fresh_outputs" if fresh else "")] = round(host["async"] / host["n"] * 1e6, 1)
-                out["step%s_host_us_in_step_wait" % ("_fresh_outputs" if fresh else "")] = round(host["wait"] / host["n"] * 1e6, 1)
+                out["step%s_host_us_in_step_async" % tag] = round(host["async"] / host["n"] * 1e6, 1)
+                out["step%s_host_us_in_step_wait" % tag] = round(host["wait"] / host["n"] * 1e6, 1)
         del env
         torch.cuda.empty_cache()
     out["note"] = ("tensors / step: ONE launch per lock-step (the step kernel draws the next action itself); step = step kernel (also "
                    "writing reward + done, 5 bytes per bin, into page-locked host memory) + stream sync; +sampler_launch: a separate "
                    "bpp_sample_feasible launch per step as in round 3; +one_finished_info / +episodes_arrays: the finished bins' (r, l, ratio, "
-                   "counter) from the 32-byte records the step kernel itself left in the step's page-locked buffer (bpp_step_out.host_fin: "
-                   "no launch, no copy, no second sync -- one flatnonzero of `done` + one gather; round 4: bpp_gather_finished, + 82 us); "
+                   "counter): without eager_infos bpp_gather_finished when somebody looks (one launch + a second sync); with eager_infos "
+                   "(make_vec_envs' setting) the compaction is enqueued behind every step kernel and step_wait()'s one sync covers it; "
                    "+scan_episodes_arrays_like_main_py: main.py:159-162 on those arrays (two deque extends per step); +scan_finished_like_main_py: a Python loop "
                    "over the ~11 % of bins that finished, two dict reads each; +running_info: counter / ratio of all bins (12 B per bin)")
     print(json.dumps(out))

@@ -144,6 +144,67 @@ DEF_LDS(ds_write_b64, (threadIdx.x >> 6) * 8192 + lane * 8)
 #define ds_bpermute_STEP(k) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(*(uint32_t *)&v[k]) : "v"(addr));
 DEF_LDS(ds_bpermute, ((lane + 1) & 63u) * 4)
 
+// ---- does a VALU instruction with few active lanes cost less issue time? (round 5: removing ~60 vector instructions that ran
+// with 4 of 64 lanes active moved the mask kernel by 1 %): v_mul_u32_u24 under a fixed EXEC mask --------------------------
+template <uint32_t LO, uint32_t HI>
+__global__ __launch_bounds__(256) void k_exec_mask(uint32_t *out, uint32_t c0) {
+    uint32_t v[8];
+    for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 8 + k + c0;
+    uint32_t c = c0 | 3u;
+    asm volatile("s_mov_b32 exec_lo, %0\n s_mov_b32 exec_hi, %1" : : "s"(LO), "s"(HI) : "exec");
+    for (int it = 0; it < ITER; ++it) {
+        REP64(mul_u24_STEP)
+    }
+    asm volatile("s_mov_b64 exec, -1" : : : "exec");
+    uint32_t s = 0;
+    for (int k = 0; k < 8; ++k) s ^= v[k];
+    if (s == 0x12345u) out[threadIdx.x] = s;
+}
+// the same with v_add_u32 (the one instruction that issues in ~2.5 cycles) and with a v_cmp + v_cndmask pair
+template <uint32_t LO, uint32_t HI>
+__global__ __launch_bounds__(256) void k_exec_mask_add(uint32_t *out, uint32_t c0) {
+    uint32_t v[8];
+    for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 8 + k + c0;
+    uint32_t c = c0 | 3u;
+    asm volatile("s_mov_b32 exec_lo, %0\n s_mov_b32 exec_hi, %1" : : "s"(LO), "s"(HI) : "exec");
+    for (int it = 0; it < ITER; ++it) {
+        REP64(add_u32_STEP)
+    }
+    asm volatile("s_mov_b64 exec, -1" : : : "exec");
+    uint32_t s = 0;
+    for (int k = 0; k < 8; ++k) s ^= v[k];
+    if (s == 0x12345u) out[threadIdx.x] = s;
+}
+
+// which instructions pay for a sparse EXEC mask (<= 8 active lanes): every VOP2 test above, once with all lanes, once with lane 0
+#define DEF_SPARSE(NAME)                                                                  \
+    template <uint32_t LO, uint32_t HI>                                                   \
+    __global__ __launch_bounds__(256) void ks_##NAME(uint32_t *out, uint32_t c0) {        \
+        uint32_t v[8];                                                                    \
+        for (int k = 0; k < 8; ++k) v[k] = threadIdx.x * 8 + k + c0;                      \
+        uint32_t c = c0 | 3u;                                                             \
+        asm volatile("s_mov_b32 exec_lo, %0\n s_mov_b32 exec_hi, %1" : : "s"(LO), "s"(HI) : "exec"); \
+        for (int it = 0; it < ITER; ++it) {                                               \
+            REP64(NAME##_STEP)                                                            \
+        }                                                                                 \
+        asm volatile("s_mov_b64 exec, -1" : : : "exec");                                  \
+        uint32_t s = 0;                                                                   \
+        for (int k = 0; k < 8; ++k) s ^= v[k];                                            \
+        if (s == 0x12345u) out[threadIdx.x] = s;                                          \
+    }
+#define lshlrev_STEP(k) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(v[k]));
+#define and_STEP(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+#define or3_STEP(k) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(v[k]) : "v"(c));
+#define mov_STEP(k) asm volatile("v_mov_b32 %0, %1" : "=v"(v[k]) : "v"(c));
+#define max_STEP(k) asm volatile("v_max_u32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+#define sub_STEP(k) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+#define xor_STEP(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+#define cvt_f32_u32_STEP(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(v[k]));
+#define add_f32_STEP(k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[k]) : "v"(c));
+DEF_SPARSE(add_u32) DEF_SPARSE(mul_u24) DEF_SPARSE(mul_lo) DEF_SPARSE(mad_u24) DEF_SPARSE(lshl_add) DEF_SPARSE(add3) DEF_SPARSE(cndmask64v)
+DEF_SPARSE(cmp) DEF_SPARSE(cvt_ubyte) DEF_SPARSE(ffbh) DEF_SPARSE(bfe) DEF_SPARSE(perm) DEF_SPARSE(fma_f32) DEF_SPARSE(lshlrev) DEF_SPARSE(and)
+DEF_SPARSE(or3) DEF_SPARSE(mov) DEF_SPARSE(max) DEF_SPARSE(sub) DEF_SPARSE(xor) DEF_SPARSE(cvt_f32_u32) DEF_SPARSE(add_f32) DEF_SPARSE(readlane)
+
 // ---- counter calibration: known byte counts in the step kernel's access widths -------------------
 __global__ __launch_bounds__(256) void k_read4(const uint32_t *in, uint32_t *out, size_t n) {  // 4 B per lane loads
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,6 +317,34 @@ int main(int argc, char **argv) {
         run("write4_chunk_per_workgroup", [&] { hipLaunchKernelGGL(k_write4_chunk, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
         run("write16_chunk_4096_workgroups", [&] { hipLaunchKernelGGL(k_write16_chunk, dim3(4096), dim3(256), 0, 0, b, bytes / 16, 7u); });
         run("copy16_half", [&] { hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, b, bytes / 32); });
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "exec")) {
+#define XM(LO, HI) {#LO " " #HI, k_exec_mask<LO, HI>, k_exec_mask_add<LO, HI>}
+        struct X { const char *name; void (*k)(uint32_t *, uint32_t); void (*ka)(uint32_t *, uint32_t); };
+        const X xs[] = {XM(0xffffffffu, 0xffffffffu), XM(0xffffffffu, 0u), XM(0xffffu, 0u), XM(0xfffu, 0u), XM(0xffu, 0u), XM(0x3fu, 0u), XM(0x1fu, 0u),
+                        XM(0xfu, 0u), XM(0x3u, 0u), XM(0x1u, 0u), XM(0x00010001u, 0x00010001u), XM(0x00030003u, 0x00030003u), XM(0x000f000fu, 0x000f000fu),
+                        XM(0x001f001fu, 0x001f001fu), XM(0x00ff00ffu, 0x00ff00ffu), XM(0x11111111u, 0x11111111u), XM(0x01010101u, 0x01010101u),
+                        XM(0x55555555u, 0x55555555u), XM(0xffff0000u, 0u), XM(0u, 0xffffu), XM(0x0000ffffu, 0x0000000fu), XM(0x80000000u, 0x1u)};
+        for (int wps : {8})
+            for (const X &x : xs) {
+                const double ms = time_kernel(x.k, wps, dout), ma = time_kernel(x.ka, wps, dout);
+                printf("{\"exec_lo_hi\": \"%s\", \"waves_per_simd\": %d, \"v_mul_u32_u24_ns_per_wave_instr\": %.3f, \"v_add_u32_ns_per_wave_instr\": %.3f}\n", x.name, wps,
+                       ms * 1e6 / ((double)wps * ITER * 64.0), ma * 1e6 / ((double)wps * ITER * 64.0));
+            }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "sparse")) {
+        struct S { const char *name; void (*full)(uint32_t *, uint32_t); void (*one)(uint32_t *, uint32_t); void (*eight)(uint32_t *, uint32_t); int per; };
+#define SP(NAME, PER) {#NAME, ks_##NAME<0xffffffffu, 0xffffffffu>, ks_##NAME<1u, 0u>, ks_##NAME<0x01010101u, 0x01010101u>, PER}
+        const S ss[] = {SP(add_u32, 1), SP(sub, 1), SP(and, 1), SP(xor, 1), SP(mov, 1), SP(lshlrev, 1), SP(max, 1), SP(mul_u24, 1), SP(mul_lo, 1), SP(mad_u24, 1),
+                        SP(lshl_add, 1), SP(add3, 1), SP(or3, 1), SP(cndmask64v, 1), SP(cmp, 1), SP(cvt_ubyte, 1), SP(cvt_f32_u32, 1), SP(ffbh, 1), SP(bfe, 1), SP(perm, 1),
+                        SP(fma_f32, 1), SP(add_f32, 1), SP(readlane, 2)};
+        for (const S &x : ss) {
+            const double n = 8.0 * ITER * 64.0 * x.per;
+            printf("{\"instr\": \"%s\", \"waves_per_simd\": 8, \"ns_all_lanes\": %.3f, \"ns_lane0_only\": %.3f, \"ns_8_lanes_strided\": %.3f}\n", x.name,
+                   time_kernel(x.full, 8, dout) * 1e6 / n, time_kernel(x.one, 8, dout) * 1e6 / n, time_kernel(x.eight, 8, dout) * 1e6 / n);
+        }
         return 0;
     }
     struct T {
