@@ -259,6 +259,58 @@ __global__ __launch_bounds__(256) void k_copy16(const uint4 *in, uint4 *out, siz
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// the step kernel's NARROW reads (round 5): what does FETCH_SIZE report for them?
+// one 4-byte load per lane, every lane its own line `stride` bytes apart (the speculative pool look-aheads: a scattered dword per bin)
+__global__ __launch_bounds__(256) void k_read4_strided(const uint32_t *in, uint32_t *out, size_t nlines, int stride_words) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = 0;
+    for (; i < nlines; i += (size_t)gridDim.x * blockDim.x) s ^= in[i * (size_t)stride_words];
+    if (s == 0x12345u) out[0] = s;
+}
+// 48-byte array-of-structs records, one record per lane as three 16-byte loads (bpp_env_state)
+__global__ __launch_bounds__(256) void k_read48_aos(const uint4 *in, uint32_t *out, size_t nrec) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = 0;
+    for (; i < nrec; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 a = in[3 * i], b = in[3 * i + 1], c = in[3 * i + 2];
+        s ^= a.x ^ b.y ^ c.z;
+    }
+    if (s == 0x12345u) out[0] = s;
+}
+// one record per FOUR lanes (the deciding wave: a bin's lead lane reads its record, the other three lanes of the bin idle)
+__global__ __launch_bounds__(256) void k_read48_aos_lead(const uint4 *in, uint32_t *out, size_t nrec) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 4;
+    const bool lead = (threadIdx.x & 3) == 0;
+    uint32_t s = 0;
+    for (; i < nrec; i += (size_t)gridDim.x * blockDim.x / 4)
+        if (lead) {
+            const uint4 a = in[3 * i], b = in[3 * i + 1], c = in[3 * i + 2];
+            s ^= a.x ^ b.y ^ c.z;
+        }
+    if (s == 0x12345u) out[0] = s;
+}
+// 100-byte tiles read as dwords by 16-lane groups (lane sl reads dwords sl and sl + 16 of its bin's tile: bpp_tile_kernel's staging)
+__global__ __launch_bounds__(256) void k_read_tile100(const uint32_t *in, uint32_t *out, size_t ntiles) {
+    const int sl = threadIdx.x & 15;
+    size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
+    uint32_t s = 0;
+    for (; b < ntiles; b += (size_t)gridDim.x * blockDim.x / 16) {
+        const uint32_t *t = in + b * 25;
+        s ^= t[sl];
+        if (sl + 16 < 25) s ^= t[sl + 16];
+    }
+    if (s == 0x12345u) out[0] = s;
+}
+// 8-byte loads, one per FOUR lanes (the deciding wave's actions)
+__global__ __launch_bounds__(256) void k_read8_lead(const uint2 *in, uint32_t *out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 4;
+    const bool lead = (threadIdx.x & 3) == 0;
+    uint32_t s = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x / 4)
+        if (lead) s ^= in[i].x;
+    if (s == 0x12345u) out[0] = s;
+}
+
 template <typename K>
 static double time_kernel(K kern, int wps, uint32_t *dout, int reps = 3) {
     hipEvent_t e0, e1;
@@ -317,6 +369,30 @@ int main(int argc, char **argv) {
         run("write4_chunk_per_workgroup", [&] { hipLaunchKernelGGL(k_write4_chunk, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
         run("write16_chunk_4096_workgroups", [&] { hipLaunchKernelGGL(k_write16_chunk, dim3(4096), dim3(256), 0, 0, b, bytes / 16, 7u); });
         run("copy16_half", [&] { hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, b, bytes / 32); });
+        // narrow reads: `bytes` in the line = USEFUL bytes (what the lanes ask for); the lines they touch are stated in the name
+        auto run_n = [&](const char *name, size_t useful, auto launch) {
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                CHECK(hipEventRecord(e0));
+                launch();
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            printf("{\"calib\": \"%s\", \"useful_bytes\": %zu, \"ms\": %.4f, \"useful_GBps\": %.1f}\n", name, useful, best, useful / best / 1e6);
+        };
+        for (int stride : {64, 128, 256}) {
+            const size_t nl = bytes / stride;
+            char nm[96];
+            snprintf(nm, sizeof nm, "read4_one_dword_per_%dB_line (%zu lines)", stride, nl);
+            run_n(nm, nl * 4, [&] { hipLaunchKernelGGL(k_read4_strided, dim3(grid), dim3(256), 0, 0, (const uint32_t *)a, dout, nl, stride / 4); });
+        }
+        run_n("read48_aos_record_per_lane (1 GiB of records)", bytes / 48 * 48, [&] { hipLaunchKernelGGL(k_read48_aos, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, dout, bytes / 48); });
+        run_n("read48_aos_record_per_4_lanes (1 GiB of records)", bytes / 48 * 48, [&] { hipLaunchKernelGGL(k_read48_aos_lead, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, dout, bytes / 48); });
+        run_n("read_tile100_dwords_by_16_lane_groups (1 GiB of tiles)", bytes / 100 * 100, [&] { hipLaunchKernelGGL(k_read_tile100, dim3(grid), dim3(256), 0, 0, (const uint32_t *)a, dout, bytes / 100); });
+        run_n("read8_one_per_4_lanes (1 GiB)", bytes, [&] { hipLaunchKernelGGL(k_read8_lead, dim3(grid), dim3(256), 0, 0, (const uint2 *)a, dout, bytes / 8); });
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "exec")) {
