@@ -9,7 +9,9 @@ import ctypes, json
 import torch, bpp_amd
 from bpp_amd import _lib
 lib = _lib.lib()
-out = {}
+if len(sys.argv) > 2 and sys.argv[1] == "--groups":     # bpp_knobs.tile_groups: groups of bins a wave of the tile kernel walks through
+    _lib.set_knobs(tile_groups=int(sys.argv[2]))
+out = {"tile_groups": _lib.get_knobs()["tile_groups"]}
 N = 200
 for size, E, rot in (((10, 10, 10), 65536, False), ((10, 10, 10), 65536, True), ((20, 20, 20), 32768, False)):
     pool = bpp_amd.sequences.cut2_pool(size, 256, seed=0)
