@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence set for the current build, one gpurun call -> gpurun_out/<tag>/ (copy what is to be judged into
-# profiles/ as r4_*): GPU suite, benches of the three single-GPU configs (+ the driver's --steps 20 with the reference
+# profiles/ as r5_*): GPU suite, benches of the three single-GPU configs (+ the driver's --steps 20 with the reference
 # baseline, + the primary pool), rocprofv3 kernel stats per config (headline leg and past-the-Infinity-Cache leg
 # separately), PMC passes per config, mask / reset kernels, drop-in step(), acc_reduce, stream-supply benches (both
 # generators) with kernel stats, 2 ranks on one device without a launcher, RCCL with one rank, bins sweep.
@@ -14,17 +14,17 @@ mkdir -p $O
 cd $R
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
-python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench.err
-python bench.py --no-cpu-baseline > $O/bench.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --rotation > $O/bench_rotation.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --size 20 20 20 --envs 32768 --pool 2048 > $O/bench_20x20x20.json 2>> $O/bench.err
-python bench.py --no-cpu-baseline --pool-file tests/golden/cut2_dataset_10.npz > $O/bench_primary_pool_cut2_dataset.json 2>> $O/bench.err
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_steps20.json 2> $O/bench.err      # the driver's command: all configs + parity gate + epsilon leg
+python bench.py --no-cpu-baseline > $O/bench.json 2>> $O/bench.err                                      # the same line at the default K = 500
+python bench.py --no-cpu-baseline --only-headline --rotation > $O/bench_rotation.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --only-headline --size 20 20 20 --envs 32768 --pool 2048 > $O/bench_20x20x20.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --only-headline --pool-file tests/golden/cut2_dataset_10.npz > $O/bench_primary_pool_cut2_dataset.json 2>> $O/bench.err
 for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768 --pool 2048"; do
   name=${cfg%%:*}; args=${cfg#*:}
   for leg in "headline:--no-past-l3" "past_l3:--past-l3-only"; do
     lname=${leg%%:*}; largs=${leg#*:}
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${name}_$lname -o run -- \
-        python $R/bench.py --no-cpu-baseline --gpu-seconds 0.5 $largs $args > $O/bench_under_rocprof_${name}_$lname.json 2>/dev/null)
+        python $R/bench.py --no-cpu-baseline --only-headline --no-parity --gpu-seconds 0.5 $largs $args > $O/bench_under_rocprof_${name}_$lname.json 2>/dev/null)
     cp $O/prof_${name}_$lname/run_kernel_stats.csv $O/kernel_stats_${name}_$lname.csv 2>/dev/null
     rm -rf $O/prof_${name}_$lname
   done
@@ -52,14 +52,15 @@ for g in mt19937 counter; do
       python $R/bench.py --no-cpu-baseline --stream --stream-rng $g --stream-depth 64 --stream-refill 30 --gpu-seconds 0.5 > /dev/null 2>&1)
   cp $O/prof_stream_$g/run_kernel_stats.csv $O/kernel_stats_stream_${g}_d64_r30_serial_schedule.csv 2>/dev/null; rm -rf $O/prof_stream_$g
 done
-BPP_BENCH_ONE_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 100 --warmup 20 --gpu-seconds 1 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_self_launched_one_device.json
-BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --warmup 20 --gpu-seconds 1 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
+BPP_BENCH_ONE_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 100 --warmup 20 --gpu-seconds 1 --only-headline 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_self_launched_one_device.json
+BPP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 8 --envs 8192 --steps 20 --warmup 5 --gpu-seconds 0.3 --no-past-l3 2> $O/bench_8ranks.err | tail -n 1 > $O/bench_8ranks_self_launched_one_device_8192_bins_each.json
+BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --only-headline --steps 100 --warmup 20 --gpu-seconds 1 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
 timeout 600 python tools/sweep_bins.py --bins 65536 262144 > $O/sweep_bins_10.jsonl 2> $O/sweep.err
 for f in bench_steps20 bench bench_rotation bench_20x20x20 bench_primary_pool_cut2_dataset; do
   python - <<PY
 import json
 try:
-    d = json.loads(open("$O/$f.json").readline()); r = d["roofline"]
+    d = json.loads([l for l in open("$O/$f.json") if l.startswith("{")][0]); r = d["roofline"]
     print("$f: %.1f M env steps/s (%.1f M past L3), %.2f us/lock-step, kernel %.2f us frac %.3f / past L3 %.2f us frac %.3f" % (
         d["value"] / 1e6, (d["value_past_l3"] or 0) / 1e6, d["ms_per_step"] * 1e3, r["launch_us"], r["frac"], r["launch_us_past_l3"] or 0, r["frac_past_l3"] or 0))
     c = d.get("cpu_baseline")

@@ -15,7 +15,7 @@ for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768 --pool 2048
   for abl in 0 1 2 3 4 8; do
     rm -rf $O/pmc_tmp
     (cd /tmp && BPP_ABLATE=$abl timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_tmp/p -o p -- \
-        python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-past-l3 --reps 3 $args > /dev/null 2>&1)
+        python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --only-headline --no-parity --no-past-l3 --reps 3 $args > /dev/null 2>&1)
     python $R/tools/pmc_summary.py $O/pmc_tmp > /dev/null 2>&1
     echo "config $name BPP_ABLATE=$abl" >> $O/lds_conflicts_by_phase.txt
     grep "^step" $O/pmc_tmp/summary.txt >> $O/lds_conflicts_by_phase.txt

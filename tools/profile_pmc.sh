@@ -11,7 +11,7 @@ cd /tmp
 run() { # name counters...
   local name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o p -- \
-      python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline ${BENCH_EXTRA:-} "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1 || echo "pass $name failed"
+      python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --only-headline --no-parity ${BENCH_EXTRA:-} "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 BENCH_ARGS=("$@")
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
