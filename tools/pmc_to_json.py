@@ -8,7 +8,13 @@ Counter handling (MI355X_MICROARCH.md "HBM", calibrated on this box with tools/u
   * FETCH_SIZE and WRITE_SIZE are in KiB and come from separate passes;
   * FETCH_SIZE reports exactly HALF of the bytes read, for 4-byte-per-lane and 16-byte-per-lane loads alike
     (1 GiB read -> 524 298 KiB) -> doubled;
-  * WRITE_SIZE is exact for 4- and 16-byte-per-lane stores (1 GiB written -> 1 048 576 KiB) -> taken as is.
+  * WRITE_SIZE is exact for 4- and 16-byte-per-lane stores (1 GiB written -> 1 048 576 KiB) -> taken as is;
+  * round 5 (profiles/r5i_counter_calibration_narrow_reads.json): the factor 2 holds for EVERY read width the step kernel uses -- 4, 8, 16
+    bytes per lane, 48-byte records read by every lane or by every fourth lane; 100-byte tiles read as dwords: 1.92 -- and a
+    SCATTERED dword that misses the L2 costs one whole 128-byte line at the fabric.  `fetch_attribution` below prices the
+    kernel's contiguous reads (tile + 48-byte record + action + the statistics row prefetched for every bin, per bin) and
+    books what is left to the three speculative pool look-aheads per bin (4 bytes each, scattered over the pool): the pool
+    is a few MB, but the 140 MB a lock-step writes keep flushing it out of the 4 MB L2s, and every miss fetches a line.
 VALU utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over all SIMDs) * 4 / (1024 SIMDs * kernel cycles),
 kernel cycles = SQ_BUSY_CYCLES / 32 shader engines.
 """
@@ -41,6 +47,12 @@ def main():
     for arg in sys.argv[1:]:
         key, path = arg.split("=", 1)
         c = parse(path)
+        dims, rot, envs = key.split("_")
+        W, L, H = (int(v) for v in dims.split("x"))
+        E = int(envs[1:])
+        contiguous = E * (W * L + 48 + 8 + 32)       # byte tile, state record, action, ep_acc row (prefetched for every bin)
+        fetched = int(2 * c["FETCH_SIZE"] * 1024)
+        extra = max(0, fetched - contiguous)
         cyc = c["SQ_BUSY_CYCLES"] / 32.0
         util = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
         out[key] = {
@@ -50,6 +62,11 @@ def main():
             "lds_instructions": int(c["SQ_INSTS_LDS"]), "waves": int(c["SQ_WAVES"]),
             "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0),
             "valu_utilisation": round(util, 3),
+            "fetch_attribution": {"contiguous_reads_bytes": contiguous, "left_over_bytes": extra,
+                                  "left_over_as_128B_lines": extra // 128, "speculative_pool_loads_per_launch": 3 * E,
+                                  "share_of_pool_loads_that_would_miss_L2": round(extra / 128.0 / (3 * E), 3),
+                                  "reading": "the left-over is what the scattered 4-byte pool look-aheads fetch when they miss the L2 (one 128-byte "
+                                             "line each, calibrated); not over-fetch of the streaming tensors"},
             "source": os.path.relpath(os.path.abspath(path), ROOT),
         }
     json.dump(out, open(out_path, "w"), indent=1)
