@@ -55,13 +55,18 @@ def pad_pool(seqs, T, term):
     return pool
 
 
-def make_stack(pool, size, rotation, E):
+def make_stack(pool, size, rotation, E, env_ids=None, env_total=None):
+    """E reference envs; env e plays the item stream of GLOBAL bin env_ids[e] of a job of env_total bins (default: bins
+    0 .. E-1 of a job of E): episode k of global bin g plays pool row (g + k * env_total) mod P (include/bpp_abi.h)."""
     term = tuple(int(v) for v in pool[0, -1, :3])
     seqs = [[tuple(int(v) for v in it[:3]) for it in s] for s in pool]
+    ids = list(range(E)) if env_ids is None else [int(v) for v in env_ids]
+    total = E if env_total is None else int(env_total)
+    assert len(ids) == E
 
     def thunk(e):
         def _t():
-            cr = ref_shims.make_replay_creator(seqs, term, env_id=e, env_total=E)
+            cr = ref_shims.make_replay_creator(seqs, term, env_id=ids[e], env_total=total)
             env = PackingGame(box_creator=cr, container_size=size, enable_rotation=rotation)
             return bench.Monitor(env, None, allow_early_resets=False)
         return _t
@@ -92,12 +97,13 @@ def exact(a, dtype):
     return b
 
 
-def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=None):
-    """One recorded rollout of the reference stack -> <out_dir or tests/golden>/<name>.npz."""
+def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=None, env_ids=None, env_total=None):
+    """One recorded rollout of the reference stack -> <out_dir or tests/golden>/<name>.npz.  env_ids / env_total: the E
+    recorded envs are the global bins env_ids of a job of env_total bins (stored in the file as `env_ids`, `env_total`)."""
     W, L, H = size
     A = W * L
     M = A * (1 + rotation)
-    dummy, venv = make_stack(pool, size, rotation, E)
+    dummy, venv = make_stack(pool, size, rotation, E, env_ids, env_total)
     rng = np.random.RandomState(seed)
     obs = venv.reset()
     mask = loop_masks(obs, size, rotation)
@@ -137,6 +143,8 @@ def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=N
                reward=np.stack(rews), done=np.stack(dones), counter=np.stack(counters), ratio=np.stack(ratios),
                ep_r=np.stack(ep_r), ep_r_raw=np.stack(ep_r_raw), ep_l=np.stack(ep_l), pool=pool,
                size=np.array(size, np.int32), rotation=np.int32(rotation))
+    if env_ids is not None:
+        rec.update(env_ids=np.asarray(env_ids, np.int64), env_total=np.int64(env_total))
     path = os.path.join(out_dir or HERE, name + ".npz")
     np.savez_compressed(path, **rec)
     nd = int(rec["done"].sum())
@@ -271,7 +279,7 @@ def live_case(spec_json):
         return
     pool = np.load(spec["pool"])["pool"]
     rollout_case(spec["name"], pool, size, bool(spec["rotation"]), spec["E"], spec["steps"], spec["seed"], spec["p_random"],
-                 out_dir=spec["out_dir"])
+                 out_dir=spec["out_dir"], env_ids=spec.get("env_ids"), env_total=spec.get("env_total"))
 
 
 def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):

@@ -19,9 +19,26 @@ CASES = {
     "live_cut2_10": dict(size=(10, 10, 10), rotation=False, E=64, steps=200, seed=41, p_random=0.06, pool=("cut2", 256)),
     "live_cut2_10_rot": dict(size=(10, 10, 10), rotation=True, E=64, steps=200, seed=42, p_random=0.06, pool=("cut2", 256)),
     "live_cut2_20": dict(size=(20, 20, 20), rotation=False, E=64, steps=200, seed=43, p_random=0.03, pool=("cut2", 96)),
+    # 192 bins SCATTERED over a full-size job of 65 536 (first / last bin, workgroup / wave / XCD-chunk boundaries, random ones): the
+    # GPU twin steps all 65 536 bins -- BASELINE config 2's launch -- and compares these against the reference's own code
+    "live_cut2_10_scattered_in_65536": dict(size=(10, 10, 10), rotation=False, E=192, steps=40, seed=45, p_random=0.06, pool=("cut2", 512),
+                                            env_total=65536),
     # (LoadBoxCreator.reset re-reads the whole .pt file, ~0.7 s per episode: a smaller case)
     "live_dataset_cut2": dict(size=(10, 10, 10), rotation=False, E=8, steps=60, seed=44, p_random=0.06, dataset="dataset/cut_2.pt"),
 }
+
+
+def scattered_ids(n, total, seed):
+    """n distinct global bin ids of a job of `total` bins, ascending: the edges (first / last bin, the bins either side of every
+    eighth of the job = the XCD chunks of the step kernel's workgroup remap, of a 16-bin workgroup and a 4-bin wave) + random ones."""
+    fixed = {0, 1, 3, 4, 15, 16, 17, total - 1, total - 2, total - 16, total - 17}
+    for k in range(1, 8):
+        fixed.update((k * total // 8 - 1, k * total // 8, k * total // 8 + 1))
+    rng = np.random.RandomState(seed)
+    ids = set(v for v in fixed if 0 <= v < total)
+    while len(ids) < n:
+        ids.add(int(rng.randint(0, total)))
+    return sorted(ids)[:n] if len(ids) > n else sorted(ids)
 
 
 def record_all(out_dir, cases=None):
@@ -43,6 +60,9 @@ def record_all(out_dir, cases=None):
             pool = bpp_amd.sequences.cut2_pool(c["size"], c["pool"][1], seed=7)
             spec["pool"] = os.path.join(out_dir, name + "_pool.npz")
             np.savez(spec["pool"], pool=pool)
+            if "env_total" in c:
+                spec["env_total"] = c["env_total"]
+                spec["env_ids"] = scattered_ids(c["E"], c["env_total"], c["seed"])
         procs[name] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py"), "--live", json.dumps(spec)],
                                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     out = {}

@@ -2,7 +2,8 @@
 copies made by oracle/make_ref.py; /root/reference does not exist on the box and is never read here).
 
 * rollouts recorded at test time, in child processes, from the reference stack (tests/live_reference.py: 64 bins x 200
-  lock-steps on 10x10x10, 10x10x10 + rotation, 20x20x20; dataset/cut_2.pt through the reference's own LoadBoxCreator),
+  lock-steps on 10x10x10, 10x10x10 + rotation, 20x20x20; dataset/cut_2.pt through the reference's own LoadBoxCreator; 192 bins
+  SCATTERED over a full-size job of 65 536 -- the GPU steps all 65 536, BASELINE config 2's launch, and those 192 are compared),
   replayed on the HIP path through all three kernel paths -- every observation, mask (both rules), reward, done,
   counter, ratio, episode return / length compared with assert_array_equal;
 * main.py:100-207 transcribed (tests/main_loop.py) with the reference's own Policy / RolloutStorage / ACKTR.update
@@ -48,6 +49,31 @@ class _Env(object):
         return out
 
 
+class _ScatteredEnv(object):
+    """The recorded bins are bins `ids` of a FULL-SIZE env (BASELINE config 2's launch: 65 536 bins, 4 096 workgroups): every
+    lock-step steps all of them -- the others with uniform-feasible draws of their own --, only the recorded ones are handed back."""
+
+    def __init__(self, bpp, pool, size, rot, ids, total, rule):
+        import torch
+        self.env = bpp.BppVecEnv(total, size, enable_rotation=bool(rot), pool=pool, mask_rule="space" if rule else "utils")
+        self.ids = torch.as_tensor(np.asarray(ids), dtype=torch.int64, device=self.env.device)
+        self.t = 0
+
+    def reset(self):
+        obs = self.env.reset()
+        return obs[self.ids].cpu().numpy(), self.env.location_masks[self.ids].cpu().numpy()
+
+    def step(self, actions):
+        import torch
+        a = self.env.sample_feasible(seed=77, step=self.t)
+        a[self.ids] = torch.as_tensor(np.asarray(actions), dtype=torch.int64, device=self.env.device)
+        self.t += 1
+        r = self.env.step_tensors(a)
+        out = {k: getattr(r, k)[self.ids].cpu().numpy() for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len")}
+        out["reward"] = r.reward[self.ids].cpu().numpy()[:, 0]
+        return out
+
+
 @pytest.mark.parametrize("path", ["tile", "rt", "generic"])
 @pytest.mark.parametrize("case", sorted(live_reference.CASES))
 def test_hip_replays_live_reference_recording(bpp, recordings, case, path):
@@ -55,7 +81,10 @@ def test_hip_replays_live_reference_recording(bpp, recordings, case, path):
                              legacy_fast=int(path == "rt"))
     try:
         g = dict(np.load(recordings[case]))
-        check_rollout(lambda pool, size, rot, E, rule: _Env(bpp, pool, size, rot, E, rule), g)
+        if "env_ids" in g:      # bins scattered over a full-size launch
+            check_rollout(lambda pool, size, rot, E, rule: _ScatteredEnv(bpp, pool, size, rot, g["env_ids"], int(g["env_total"]), rule), g)
+        else:
+            check_rollout(lambda pool, size, rot, E, rule: _Env(bpp, pool, size, rot, E, rule), g)
         assert g["done"].sum() > (200 if g["actions"].shape[1] >= 64 else 30)
     finally:
         bpp._lib.set_knobs(**old)
