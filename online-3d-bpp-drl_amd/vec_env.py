@@ -216,6 +216,8 @@ class LazyInfos(object):
         return (self[i] for i in range(len(self)))
 
     def done_indices(self):
+        if self._fin is not None:          # (eager_infos: the compaction's bin list is the answer, ascending)
+            return self._fin[0]
         return np.flatnonzero(self._done_mask())
 
 
