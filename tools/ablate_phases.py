@@ -3,7 +3,8 @@ BPP_HIP_LIB=.../libbpp_hip_abl.so): the mask-only kernel (fixed inputs -- skippi
 see) and the step kernel (skipping the prefix image / the candidates changes the masks and therefore the episodes: those rows
 are indicative only) with phases switched off through bpp_knobs.ablate, 200 launches back to back between one pair of HIP
 events.  Bits: 1 prefix image, 2 candidate passes, 4 mask store, 8 observation + heightmap store, 16 everything (empty
-kernel), 32 deciding wave, 64 staging loads (step kernel)."""
+kernel), 32 deciding wave, 64 staging loads (step kernel).  Bit 32 in the FULL kernel is not "the cost of deciding": without
+decisions no bin gets an item and the candidate passes fall away too (step abl=32 ~ step abl=3); compare abl=15 with abl=111."""
 import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ctypes, json
 import torch, bpp_amd
