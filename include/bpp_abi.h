@@ -13,10 +13,10 @@
  *
  * Ownership: the caller allocates and owns every buffer (PyTorch-ROCm tensors in practice); the
  * library never allocates or frees device memory.  Process-global state: the thread-local last-error
- * string, the launch-shape knobs (bpp_knobs, which never change results) and -- only once
- * bpp_rollout_uniform_stream has run its refills beside the lock-steps -- one high-priority side stream
- * plus three events per device, created on first use, guarded by a mutex and kept for the life of the
- * process.  Kernels are enqueued on `stream` and the calls return without synchronising.
+ * string and the launch-shape knobs (bpp_knobs, which never change results); nothing else -- the side stream
+ * and events of bpp_rollout_uniform_stream's overlapped schedule belong to the caller (bpp_side_create /
+ * bpp_side_destroy, ABI v14; rounds 3-4 kept one set per device inside the library).  Kernels are
+ * enqueued on `stream` and the calls return without synchronising.
  *
  * Error convention: 0 = success; >0 = hipError_t from the runtime; <0 = BPP_E_* below.  A message
  * is available from bpp_last_error().  An infeasible or out-of-range *action* is not an error: it
@@ -403,12 +403,17 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream);
 
 /* bpp_rollout_uniform over a ring pool: additionally refills the ring after every `refill_every` lock-steps
- * (1 <= refill_every <= depth - 3).  With depth >= 2 * refill_every + 3 (and the stream_overlap knob on) the refills run on
- * a library-owned high-priority stream BESIDE the following lock-steps (a chunk of lock-steps starts once the refill
- * issued two chunks earlier is complete); everything enqueued on `stream` after the call sees a full ring, as after
- * bpp_stream_refill.  Results are the same either way. */
+ * (1 <= refill_every <= depth - 3; depth - 4 with a seq_cache).  With `side` != NULL, depth >= 2 * refill_every + 3 (+ 4) and the
+ * stream_overlap knob on, the refills run on the side's high-priority stream BESIDE the following lock-steps (a chunk of
+ * lock-steps starts once the refill issued two chunks earlier is complete); everything enqueued on `stream` after the call
+ * sees a full ring, as after bpp_stream_refill.  side == NULL: the refills run on `stream` between the lock-steps.  Results are
+ * the same either way.
+ * bpp_side_create: one high-priority stream + three events on the calling thread's CURRENT device, owned by the caller (one
+ * per env; two calls that share a side must be ordered by the caller); bpp_side_destroy(NULL) is a no-op. */
+int bpp_side_create(void **side);
+int bpp_side_destroy(void *side);
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed,
-                               uint64_t step0, int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream);
+                               uint64_t step0, int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *side, void *stream);
 
 /* Device-side replacement of the training loop's per-bin `infos` scan (main.py:159-162: for every
  * finished episode append info['episode']['r'] and info['ratio'] to the logging deques):

@@ -27,7 +27,7 @@ REDUCE_SCRATCH_BYTES = REDUCE_LANES * 4 * 8 + 64
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override", "bpp_side_create", "bpp_side_destroy"]
 
 
 class Batch(ctypes.Structure):
@@ -166,7 +166,9 @@ def lib():
         L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
                                                  ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
-                                                 ctypes.c_void_p]
+                                                 ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_side_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        L.bpp_side_destroy.argtypes = [ctypes.c_void_p]
         L.bpp_launch_info.argtypes = [ctypes.c_int32] * 5 + [ctypes.POINTER(ctypes.c_int32)]
         L.bpp_get_knobs.argtypes = [ctypes.POINTER(Knobs)]
         L.bpp_set_knobs.argtypes = [ctypes.POINTER(Knobs)]

@@ -2763,37 +2763,14 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
 }  // extern "C"
 
 namespace {
-// One high-priority stream per device for refills that run beside the step kernels (bpp_rollout_uniform_stream).
+// bpp_side: what the overlapped schedule of bpp_rollout_uniform_stream needs beside the caller's stream -- ONE high-priority stream for
+// the refills and three events -- created and owned by the CALLER (bpp_side_create / bpp_side_destroy; one per env), so that the
+// library keeps no per-device state of its own (rounds 3-4 kept one lazily created set per device behind a mutex).
 struct SideStream {
     hipStream_t stream;
     hipEvent_t stepped, refilled[2];
-    std::mutex in_use;     // one bpp_rollout_uniform_stream at a time per device: the events are shared
+    int device;
 };
-SideStream *side_stream() {
-    static std::mutex mu;
-    static SideStream *per_device[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!per_device[dev]) {
-        SideStream *ss = new SideStream();
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        // (a CU mask on this stream -- refills confined to 32 .. 128 CUs so that the others keep all their workgroup slots
-        // for the step kernel -- was measured: 0.33 - 0.74 G env steps/s against 1.17 - 1.28 G without, the refill becomes
-        // the critical path)
-        bool ok = hipStreamCreateWithPriority(&ss->stream, hipStreamNonBlocking, greatest) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&ss->stepped, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&ss->refilled[0], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&ss->refilled[1], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            delete ss;
-            return nullptr;
-        }
-        per_device[dev] = ss;
-    }
-    return per_device[dev];
-}
 
 int check_stream(const bpp_stream *s) {
     if (!s || !s->ring || !s->mt || !s->work || !s->gen_next || !s->state) return fail(BPP_E_BADARG, "bpp_stream: NULL pointer");
@@ -2901,8 +2878,52 @@ extern "C" {
 
 int bpp_stream_refill(const bpp_stream *s, void *stream) { return stream_refill(s, stream, 0, 0); }
 
+int bpp_side_create(void **side) {
+    if (!side) return fail(BPP_E_BADARG, "bpp_side_create: NULL pointer");
+    *side = nullptr;
+    SideStream *ss = new SideStream();
+    if (hipGetDevice(&ss->device) != hipSuccess) {
+        delete ss;
+        return fail(BPP_E_BADARG, "bpp_side_create: no current device");
+    }
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // (a CU mask on this stream -- refills confined to 32 .. 128 CUs so that the others keep all their workgroup slots
+    // for the step kernel -- was measured: 0.33 - 0.74 G env steps/s against 1.17 - 1.28 G without, the refill becomes
+    // the critical path)
+    hipError_t e = hipStreamCreateWithPriority(&ss->stream, hipStreamNonBlocking, greatest);
+    if (e != hipSuccess) {
+        delete ss;
+        return hip_fail(e, "hipStreamCreateWithPriority");
+    }
+    hipEvent_t *ev[3] = {&ss->stepped, &ss->refilled[0], &ss->refilled[1]};
+    for (int k = 0; k < 3; ++k) {
+        e = hipEventCreateWithFlags(ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int j = 0; j < k; ++j) (void)hipEventDestroy(*ev[j]);
+            (void)hipStreamDestroy(ss->stream);
+            delete ss;
+            return hip_fail(e, "hipEventCreateWithFlags");
+        }
+    }
+    *side = ss;
+    return 0;
+}
+
+int bpp_side_destroy(void *side) {
+    if (!side) return 0;
+    SideStream *ss = (SideStream *)side;
+    (void)hipStreamSynchronize(ss->stream);
+    (void)hipEventDestroy(ss->stepped);
+    (void)hipEventDestroy(ss->refilled[0]);
+    (void)hipEventDestroy(ss->refilled[1]);
+    hipError_t e = hipStreamDestroy(ss->stream);
+    delete ss;
+    return e == hipSuccess ? 0 : hip_fail(e, "hipStreamDestroy");
+}
+
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
-                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
+                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *side_handle, void *stream) {
     if (!b || !s) return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: NULL pointer");
     const int behind = b->seq_cache ? 4 : 3;   // rows a step launch may touch from the current one on (a cache line refers to the row after next)
     if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - behind)
@@ -2915,10 +2936,13 @@ int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int6
     // two rows ahead, so it needs m >= R + 3 to get through the chunk that runs beside the refill and m + need >= 2 R + 3
     // to get through the one after (this refill complete, the next one running).  The scan guarantees the second
     // (need >= 2 R + 3 - m, `urgent`), which also gives the first for the next scan: m' >= m + need - R >= R + 3.
-    SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + behind) ? side_stream() : nullptr;
+    SideStream *side = (current_knobs().stream_overlap && s->depth >= 2 * refill_every + behind) ? (SideStream *)side_handle : nullptr;
     hipStream_t main = (hipStream_t)stream;
-    std::unique_lock<std::mutex> hold;
-    if (side) hold = std::unique_lock<std::mutex>(side->in_use);
+    if (side) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != side->device)
+            return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: the bpp_side was created on another device");
+    }
     int32_t chunk = 0;
     for (int32_t done = 0; rc == 0 && done < nsteps; done += refill_every, ++chunk) {
         const int32_t n = nsteps - done < refill_every ? nsteps - done : refill_every;

@@ -413,6 +413,7 @@ class BppVecEnv(object):
         self._pending = None
         self._tstart = time.time()
         self.monitor = None        # MonitorCsv (make_vec_envs with a log_dir): step_wait() appends the finished episodes' rows
+        self._side = None          # bpp_side (rollout_uniform in streaming mode): created on first use
         self.closed = False
 
     MAX_STAGING = 16     # page-locked host buffers (29 B per bin each) handed out at the same time, at most
@@ -682,9 +683,12 @@ class BppVecEnv(object):
         self._serial += int(nsteps)
         if self._stream is not None:
             self.refill()
+            if self._side is None:      # the overlapped schedule's side stream + events: this env's own (bpp_side_create), released in close()
+                self._side = ctypes.c_void_p()
+                _lib.check(self.lib.bpp_side_create(ctypes.byref(self._side)))
             _lib.check(self.lib.bpp_rollout_uniform_stream(self._batch_ref, ctypes.byref(self._plain(self._out)), actions.data_ptr(), int(seed),
                                                            int(step0), int(nsteps), ctypes.byref(self._stream),
-                                                           self.refill_every, self._stream_ptr()))
+                                                           self.refill_every, self._side, self._stream_ptr()))
             return self._res
         _lib.check(self.lib.bpp_rollout_uniform(self._batch_ref, ctypes.byref(self._plain(self._out)), actions.data_ptr(), int(seed),
                                                 int(step0), int(nsteps), self._stream_ptr()))
@@ -777,7 +781,20 @@ class BppVecEnv(object):
     def close(self):
         if self.monitor is not None:
             self.monitor.close()
+        self._release_side()
         self.closed = True
+
+    def _release_side(self):
+        side, self._side = getattr(self, "_side", None), None
+        if side is not None and side.value:
+            try:
+                with torch.cuda.device(self.device):
+                    self.lib.bpp_side_destroy(side)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown: the runtime may be gone already
+                pass
+
+    def __del__(self):
+        self._release_side()
 
     def render(self, mode="human"):
         raise NotImplementedError("BppVecEnv has no renderer (the reference's PackingGame.render is a no-op too)")

@@ -784,8 +784,21 @@ int bpp_stream_refill(const bpp_stream *s, void *stream) {
     return 0;
 }
 
+int bpp_side_create(void **side) {      /* host twin: nothing to create; a non-NULL token so that callers can tell success */
+    static int token;
+    if (!side) return fail(BPP_E_BADARG, "bpp_side_create: NULL pointer");
+    *side = &token;
+    return 0;
+}
+
+int bpp_side_destroy(void *side) {
+    (void)side;
+    return 0;
+}
+
 int bpp_rollout_uniform_stream(const bpp_batch *b, const bpp_step_out *out, int64_t *actions, uint64_t seed, uint64_t step0,
-                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *stream) {
+                               int32_t nsteps, const bpp_stream *s, int32_t refill_every, void *side, void *stream) {
+    (void)side;
     if (!b || !s) return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: NULL pointer");
     if (b->pool_mode != BPP_POOL_RING || refill_every < 1 || refill_every > s->depth - 3)
         return fail(BPP_E_BADARG, "bpp_rollout_uniform_stream: needs a ring pool and 1 <= refill_every <= depth - 3");

@@ -111,7 +111,9 @@ def lib():
         L.bpp_stream_refill.argtypes = [ctypes.POINTER(Stream), ctypes.c_void_p]
         L.bpp_rollout_uniform_stream.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_uint64,
                                                  ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(Stream), ctypes.c_int32,
-                                                 ctypes.c_void_p]
+                                                 ctypes.c_void_p, ctypes.c_void_p]
+        L.bpp_side_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        L.bpp_side_destroy.argtypes = [ctypes.c_void_p]
         L.bpp_episode_stats.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -243,8 +245,12 @@ def rollout_uniform(env, seed, step0, nsteps):
     a = np.zeros(env.E, np.int64)
     if env.stream is not None:
         env.refill()
+        side = getattr(env, "_side", None)          # bpp_side_create once per env: the overlapped schedule's stream + events
+        if side is None:
+            side = env._side = ctypes.c_void_p()
+            _check(lib().bpp_side_create(ctypes.byref(side)))
         _check(lib().bpp_rollout_uniform_stream(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
-                                                int(nsteps), ctypes.byref(env.stream), env.refill_every, None))
+                                                int(nsteps), ctypes.byref(env.stream), env.refill_every, side, None))
         return env.out, a
     _check(lib().bpp_rollout_uniform(ctypes.byref(env._b), ctypes.byref(env._o), _p(a), int(seed), int(step0),
                                      int(nsteps), None))

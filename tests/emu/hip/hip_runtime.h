@@ -70,6 +70,8 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
     *e = nullptr;
     return hipSuccess;
 }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 enum { hipMemcpyDeviceToHost = 2 };
