@@ -463,6 +463,38 @@ def test_gpu_stream_checkpoints_are_validated_on_load():
     assert odd.stream_spec["cache"] is False and odd.refill_every == 5
 
 
+@pytest.mark.gpu
+def test_gpu_two_streaming_envs_in_one_process_own_their_side_streams():
+    """ABI v14: the side stream + events of the overlapped refill schedule belong to the env (bpp_side_create), not to a per-device
+    set inside the library: two streaming envs of one process, driven in turns, each equal what it does alone; close() releases."""
+    import torch
+    import bpp_amd
+    size = (10, 10, 10)
+
+    def make(seed):
+        return bpp_amd.BppVecEnv(2048, size, stream=dict(bound=(2, 5), seed=seed, depth=32, refill_every=14, rng="counter"))
+
+    def drive(envs, chunks=3, n=45):
+        for e in envs:
+            e.reset()
+        for c in range(chunks):
+            for e in envs:
+                e.rollout_uniform(seed=3, step0=c * n, nsteps=n)
+        torch.cuda.synchronize()
+        return [(e.hmap.cpu().numpy().copy(), e.state.cpu().numpy().copy(), e.ep_acc.cpu().numpy().copy()) for e in envs]
+
+    a, b = make(1), make(2)
+    both = drive([a, b])
+    assert a._side is not None and b._side is not None and a._side.value != b._side.value
+    alone = drive([make(1)]) + drive([make(2)])
+    for got, want in zip(both, alone):
+        for x, y in zip(got, want):
+            np.testing.assert_array_equal(x, y)
+    assert int(both[0][1][:, 1].sum()) > 2048          # episodes went by
+    a.close(), b.close()
+    assert a._side is None and b._side is None
+
+
 def test_emulated_row_cache_answers_the_look_aheads(emu, oracle):
     """bpp_batch.seq_cache is not just harmless, it works: under the benchmark's policy (fused uniform-feasible draw) all
     but the first look-aheads of a rollout are answered by the bins' cache lines -- the ring is read only while the first
