@@ -14,15 +14,19 @@ SRC = os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_kernels.hip")
 DEPS = [SRC, os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_tile_kernel.inl"), os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_tile_body.inl"),
         os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_stream_gen.inl"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.join(ROOT, "include", "bpp_abi.h"), os.path.join(ROOT, "include", "bpp_gen.inl")]
-LIB = os.path.join(HERE, "libbpp_emu.so")
+LIB = os.path.join(HERE, "libbpp_emu.so" if not os.environ.get("BPP_EMU_DEFINES") else
+                   "libbpp_emu.so." + "".join(c if c.isalnum() else "_" for c in os.environ["BPP_EMU_DEFINES"]))
 
 
 def build(force=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
     tmp = LIB + ".tmp.%d" % os.getpid()
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-w", "-fPIC", "-shared", "-I", HERE,
-                           "-x", "c++", os.path.join(HERE, "emu_runtime.cpp"), "-o", tmp, "-lpthread"])
+    # BPP_EMU_DEFINES="-DX -DY": emulate an A/B build of the product source (tools/build_variant.sh's -D switches); the library is
+    # then rebuilt on every change of that variable because it is a file of its own
+    extra = os.environ.get("BPP_EMU_DEFINES", "").split()
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-w", "-fPIC", "-shared", "-I", HERE] + extra +
+                          ["-x", "c++", os.path.join(HERE, "emu_runtime.cpp"), "-o", tmp, "-lpthread"])
     os.replace(tmp, LIB)
     return LIB
 
