@@ -439,7 +439,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
                 const int lx = myrec.place & 255u, ly = (myrec.place >> 8) & 255u, x = (myrec.place >> 16) & 255u, y = myrec.place >> 24;
                 uint8_t *hb = hm + el * A + lx * L + ly;
                 const uint8_t top = (uint8_t)(myrec.flags >> 8);
-#ifndef BPP_AB_FILL_LOOPS
                 if (x <= G && y <= 5) {
                     // the footprints CUT-2 / RS sequences consist of: one row per lane, five unconditional byte stores whose
                     // offsets are clamped to the row (the surplus ones rewrite its last byte) -- no loop, no predicate per byte
@@ -449,7 +448,6 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
                         r[0] = top, r[min(1, y1)] = top, r[min(2, y1)] = top, r[min(3, y1)] = top, r[min(4, y1)] = top;
                     }
                 } else
-#endif
                 for (int a = sl; a < x; a += G)
                     for (int b = 0; b < y; ++b) hb[a * L + b] = top;
             }

@@ -104,27 +104,6 @@ constexpr SlotTable<W, L> make_slot_table() {
 __constant__ const SlotTable<10, 10> kSlotTable10 = make_slot_table<10, 10>();
 __constant__ const SlotTable<20, 20> kSlotTable20 = make_slot_table<20, 20>();
 
-#ifdef BPP_AB_SLOT_COMPUTE   // A/B build only (tools/build_variant.sh): round 4's form -- everything computed per launch and slot
-template <int W, int L>
-__device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[7]) {
-    constexpr int PW = L + 1;
-    const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-    const int x = rot ? iy : ix, y = rot ? ix : iy;
-    const bool valid = (uint32_t)(x - 1) < (uint32_t)W && (uint32_t)(y - 1) < (uint32_t)L;
-    const int nj = valid ? L - y + 1 : 1, nv = valid ? (W - x + 1) * nj : 0;
-    const uint32_t area = valid ? (uint32_t)(x * y) : 0u;
-    const uint32_t t95 = ((19u * area * 0xCCCDu) >> 20) + 1u, t85 = ((17u * area * 0xCCCDu) >> 20) + 1u, t50 = (area >> 1) + 1u;
-    const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
-    const bool big = x > kTileX || y > kTileY;
-    w[0] = kCandMagic.v[nj];
-    w[1] = (uint32_t)nv | ((uint32_t)nj << 11) | ((uint32_t)valid << 28) | ((uint32_t)big << 29) | ((uint32_t)(x == y && valid) << 31);
-    w[2] = (uint32_t)(x * PW) | ((uint32_t)y << 16);
-    w[3] = (uint32_t)max((x - 1) * L, 0) | ((uint32_t)max(y - 1, 0) << 16);
-    w[4] = t95 | (t85 << 16);
-    w[5] = t50 | ((uint32_t)x << 16) | ((uint32_t)y << 24);
-    w[6] = (hz1 << 16) | ((uint32_t)fresh << 30) | ((uint32_t)(rot_kernel && rot == 1) << 31);
-}
-#else
 template <int W, int L>
 __device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fresh, bool rot_kernel, int H, uint32_t w[7]) {
     static_assert((W == 10 && L == 10) || (W == 20 && L == 20), "a slot table exists for the tile geometries only");
@@ -143,7 +122,6 @@ __device__ __forceinline__ void make_slot_words(uint32_t item, int rot, bool fre
     w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w, w[4] = hi.x, w[5] = hi.y;
     w[6] = ((uint32_t)max(H - (int)z + 1, 0) << 16) | ((uint32_t)fresh << 30) | ((uint32_t)(rot_kernel && rot == 1) << 31);
 }
-#endif
 
 template <int W, int L, int K, bool ROT, int EPW, int NIT>
 struct TileGeo {
