@@ -232,7 +232,10 @@ typedef struct bpp_knobs {
     int32_t tile_groups;      /* bpp_tile_kernel: groups of bins a wave walks through, 1 / 2 / 4; 0 = by size (1, or 2 / 4
                                  once a launch's outputs exceed the Infinity Cache) */
     int32_t stream_legacy;    /* bpp_stream_refill: 1 = the one-lane-per-bin refill kernel also where the four-kernel
-                                 pipeline (scan / pretwist / cut / sort) applies                                          */
+                                 pipeline (scan / pretwist / cut / sort) applies; counter generator only: 2 = scan / cut
+                                 per bin / sort where the rows pipeline (scan / cut and rank per sequence) applies,
+                                 3 = the rows pipeline with list and staging capacities so small that most rows take
+                                 its second attempt (tests)                                                               */
     int32_t stream_overlap;   /* bpp_rollout_uniform_stream: 1 (default) = with depth >= 2 * refill_every + 3 the refills
                                  run on a high-priority side stream beside the next refill_every lock-steps, 0 = on
                                  the caller's stream between the lock-steps                                    */

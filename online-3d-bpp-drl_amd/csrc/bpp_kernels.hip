@@ -2788,9 +2788,11 @@ int check_stream(const bpp_stream *s) {
 // rows the sort kernel can stage in LDS, and a cut-kernel workgroup that fits the LDS of a CU.
 struct StreamPlan {
     bool fast;
-    int maxn, cap, nsp, nslots, fb;
-    size_t off_jobs, off_target, off_rows, off_spill, off_twist, fast_bytes, legacy_bytes, cut_lds, sort_lds;
+    bool rows;              // counter generator: the rows pipeline (one lane per sequence, ranked in the lane) fits
+    int maxn, cap, nsp, nslots, fb, stage;
+    size_t off_jobs, off_target, off_rows, off_spill, off_twist, fast_bytes, legacy_bytes, cut_lds, sort_lds, rows_lds;
 };
+constexpr size_t kRowsLdsMost = 32 * 1024;   // LDS of a rows-pipeline wave; beyond it the two-kernel pipeline (cut per bin, sort) runs
 StreamPlan plan_stream(const bpp_stream *s) {
     StreamPlan p{};
     const size_t E = (size_t)s->num_envs;
@@ -2805,6 +2807,10 @@ StreamPlan plan_stream(const bpp_stream *s) {
     p.off_twist = (p.off_spill + (size_t)2 * p.nsp * p.nslots * 4 + 15) & ~(size_t)15;
     p.fast_bytes = p.off_twist + (size_t)(p.nslots / 64) * kTwistWords * 4;     // one twist scratch per cut wave
     p.fb = stream_field_bits(s->W, s->L, s->H);
+    p.stage = stream_rows_stage_cap(s->W, s->L, s->H, s->bound_lo, s->bound_hi, p.maxn);
+    p.rows_lds = stream_rows_lds_bytes(p.cap, p.stage, p.fb, s->H);
+    p.rows = s->rng == BPP_STREAM_RNG_COUNTER && p.rows_lds <= kRowsLdsMost &&
+             (size_t)3 * (p.maxn + 2) + 2 <= stream_rows_lds_entries(p.cap, p.stage);     // a lane served alone holds any sequence
     p.legacy_bytes = (size_t)stream_work_entries(s->W, s->L, s->H, s->bound_lo) * E * 8;
     p.cut_lds = (size_t)stream_cut_lds_bytes(p.cap, p.fb);
     p.sort_lds = (size_t)4 * (s->pool_len + 256) * 4;
@@ -2843,20 +2849,33 @@ int stream_refill(const bpp_stream *s, void *stream, int kmax, int urgent) {
     if (rc) return rc;
     const StreamPlan p = plan_stream(s);
     hipStream_t st = (hipStream_t)stream;
-    if (!p.fast || current_knobs().stream_legacy) {
+    if (!p.fast || current_knobs().stream_legacy == 1) {
         hipLaunchKernelGGL(stream_refill_kernel, dim3((s->num_envs + kStreamLanes - 1) / kStreamLanes), dim3(kStreamLanes),
                            (size_t)kStreamLdsWords * kStreamLanes * 4, st, *s);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
     }
     unsigned char *base = (unsigned char *)s->work;
-    const StreamWork w{(int32_t *)base, (int32_t *)(base + p.off_jobs), (int32_t *)(base + p.off_target), (int64_t *)(base + p.off_rows),
-                       (uint32_t *)(base + p.off_spill), (uint32_t *)(base + p.off_twist), p.cap, p.nsp, p.nslots, p.maxn, p.fb, kmax, urgent};
+    const StreamWork w0{(int32_t *)base, (int32_t *)(base + p.off_jobs), (int32_t *)(base + p.off_target), (int64_t *)(base + p.off_rows),
+                       (uint32_t *)(base + p.off_spill), (uint32_t *)(base + p.off_twist), p.cap, p.nsp, p.nslots, p.maxn, p.fb, kmax, urgent, p.stage};
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     const int E = s->num_envs;
     hipLaunchKernelGGL(stream_scan_kernel, dim3((E + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 2 * (kScanThreads / 64) * 4 * sizeof(int), st,
-                       *s, w);
+                       *s, w0);
+    if (p.rows && current_knobs().stream_legacy != 2) {     // counter generator, one lane per sequence, no sort kernel
+        StreamWork w = w0;
+        if (current_knobs().stream_legacy == 3) w.cap = w.cap < 10 ? w.cap : 10, w.stage = w.stage < 24 ? w.stage : 24;
+        const int64_t waves = ((int64_t)E * s->depth + 63) / 64;
+        // one wave per 64 rows, all at once: a grid bounded to 256 / 512 / 1 024 waves that walk through the rows -- the refill
+        // spread over more of the window -- costs the lock-steps beside it MORE (profiles/r5x_*: -10 / -6 / -2 %)
+        const unsigned grid = (unsigned)(waves < 8192 ? waves : 8192);
+        if (p.fb == 4) hipLaunchKernelGGL(stream_cut_rows_kernel<4>, dim3(grid), dim3(64), p.rows_lds, st, *s, w);
+        else hipLaunchKernelGGL(stream_cut_rows_kernel<8>, dim3(grid), dim3(64), p.rows_lds, st, *s, w);
+        e = hipGetLastError();
+        return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+    }
+    const StreamWork &w = w0;
     if (s->rng == BPP_STREAM_RNG_COUNTER) {      // no generator state: nothing to regenerate, the lists are all the LDS a cut wave needs
         const size_t lds = (size_t)stream_cut_lds_bytes(p.cap, p.fb) - (size_t)64 * kRingStride;
         if (p.fb == 4) hipLaunchKernelGGL(stream_cut_ctr_kernel<4>, dim3(p.nslots / 64), dim3(64), lds, st, *s, w);

@@ -273,7 +273,7 @@ __host__ __device__ inline uint32_t mt_temper(uint32_t y) {
 // generator and Python's random module).
 // ======================================================================================================================
 struct StreamWork {        // views into bpp_stream.work (see plan_stream)
-    int32_t *hdr;          // [16]: jobs in bucket 0..2, rows to sort
+    int32_t *hdr;          // [16]: jobs in bucket 0..2, rows rewritten
     int32_t *jobs;         // [3][E]: local bin ids needing 1 / 2 / >= 3 sequences
     int32_t *target;       // [E]: gen_next every bin is brought to (the scan's reading of episode + depth: the step
                            //      kernels may be running beside the refill, the kernels must agree on one value)
@@ -284,6 +284,7 @@ struct StreamWork {        // views into bpp_stream.work (see plan_stream)
     int32_t fb;            // bits per field of a pending / unsorted box (stream_field_bits)
     int32_t kmax, urgent;  // kmax > 0: a bin gets at most kmax sequences per refill unless that leaves it fewer than
                            // `urgent` rows from its current episode (then as many as it takes); 0: always all depth rows
+    int32_t stage;         // stream_cut_rows_kernel: boxes a lane's staging column holds
 };
 constexpr int kRowHdr = 2;             // entries in front of a ring row's items (include/bpp_abi.h): item 1 of the NEXT row and
                                        // item 0 of the row after it -- the look-ahead a step needs, in the line it reads anyway
@@ -431,12 +432,12 @@ __global__ __launch_bounds__(256) void stream_pretwist_kernel(bpp_stream s, Stre
 
 // The LDS part of a lane's two pending lists (+ one dummy entry): entry w of this lane at index w * 64 of an array of
 // half-words (FB = 4) or words (FB = 8).
-template <int FB>
+template <int FB, int STRIDE = 64>
 struct ListCol {
     using T = typename std::conditional<FB == 4, uint16_t, uint32_t>::type;
-    T *p;               // &array[lane]
-    __device__ __forceinline__ uint32_t get(uint32_t w) const { return (uint32_t)p[w * 64]; }
-    __device__ __forceinline__ void set(uint32_t w, uint32_t v) const { p[w * 64] = (T)v; }
+    T *p;               // &array[lane]  (STRIDE 1: a lane that has the array to itself, stream_cut_rows_kernel's second attempt)
+    __device__ __forceinline__ uint32_t get(uint32_t w) const { return (uint32_t)p[w * STRIDE]; }
+    __device__ __forceinline__ void set(uint32_t w, uint32_t v) const { p[w * STRIDE] = (T)v; }
 };
 
 // the pending lists of one lane with their continuation in global memory: list r (0 / 1), entry i
@@ -822,8 +823,35 @@ struct CtrLane {
 
 // One visit for a lane whose lists are certain to stay inside LDS: mdCreator.py:59-100 + :120-130 without divergent
 // branches (the one that exists -- a rejected draw -- is taken by nobody in 2^32 / lim - 1 of 2^32 / lim cases).
-template <int FB>
-__device__ __forceinline__ uint32_t cut_visit_ctr(CtrLane &c, const ListCol<FB> col, int cap, uint32_t act, uint32_t lo, uint32_t hi) {
+// Where a visit's finished boxes go: straight into the ring row, unsorted (the sort kernel ranks them later) ...
+struct EmitToRow {
+    uint32_t *row;
+    __device__ __forceinline__ void operator()(uint32_t m, uint32_t nv, uint32_t v) const {
+        if (m) row[nv] = v;
+    }
+};
+// ... or into the lane's staging column in LDS (stream_cut_rows_kernel, which ranks them itself); entry `dummy` takes the
+// stores that do not apply;
+// there it is also counted (level `nolevel` for the stores that do not apply).  Level counters of a lane: two 16-bit counters
+// per word -- a row has fewer than 2 048 boxes --, level l in half l & 1 of word (l >> 1) * 64.
+__device__ __forceinline__ uint32_t level_count(uint32_t *cnt, uint32_t level) {      // returns the level's count before
+    const uint32_t sh = (level & 1u) * 16u;
+    return (atomicAdd(&cnt[(level >> 1) * 64], 1u << sh) >> sh) & 0xffffu;
+}
+template <class Col, int FB>
+struct EmitToStage {
+    Col st;
+    uint32_t *cnt;
+    uint32_t dummy, nolevel;
+    __device__ __forceinline__ void operator()(uint32_t m, uint32_t nv, uint32_t v) const {
+        st.set(m_sel(m, nv, dummy), v);
+        const uint32_t level = m_sel(m, v >> (3 * FB), nolevel);
+        atomicAdd(&cnt[(level >> 1) * 64], 1u << ((level & 1u) * 16u));
+    }
+};
+
+template <int FB, class Col, class Emit>
+__device__ __forceinline__ uint32_t cut_visit_ctr(CtrLane &c, const Col col, int cap, uint32_t act, uint32_t lo, uint32_t hi, const Emit emit) {
     constexpr uint32_t FM = (1u << FB) - 1u;
     const uint32_t dummy = 2u * (uint32_t)cap;
     const uint32_t abase = (uint32_t)cap & (0u - (uint32_t)c.side), bbase = (uint32_t)cap - abase;
@@ -848,9 +876,9 @@ __device__ __forceinline__ uint32_t cut_visit_ctr(CtrLane &c, const ListCol<FB> 
     const uint32_t me1 = msplit & monly & ~m_lt(hi, p1), me2 = msplit & monly & ~m_lt(hi, p2);   // is_valid, :110-115
     const uint32_t mq1 = msplit & ~me1, mq2 = msplit & ~me2;
     uint32_t nv = (uint32_t)c.nv, tail_a = (uint32_t)c.tail_a, tail_b = (uint32_t)c.tail_b, i = (uint32_t)c.i;
-    if (me1) c.row[nv] = c1;
+    emit(me1, nv, c1);
     nv -= me1;
-    if (me2) c.row[nv] = c2;
+    emit(me2, nv, c2);
     nv -= me2;
     col.set(m_sel(mfail, bbase + tail_b, dummy), box);            // stays in invalid_box for the next pass
     tail_b -= mfail;
@@ -957,7 +985,7 @@ __global__ __launch_bounds__(64) void stream_cut_ctr_kernel(bpp_stream s, Stream
         if (__ballot(active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap))) {   // wave-uniform: a list may leave LDS
             finished = active ? cut_visit_ctr_general<FB>(c, pend, lo, hi) : false;
         } else {
-            finished = cut_visit_ctr<FB>(c, col, cap, active ? ~0u : 0u, lo, hi) != 0u;
+            finished = cut_visit_ctr<FB>(c, col, cap, active ? ~0u : 0u, lo, hi, EmitToRow{c.row}) != 0u;
         }
         if (finished) {
             c.row[T - 1 - kRowHdr] = (uint32_t)c.nv;  // (the row's last entry) length for the sort kernel, which restores the terminator
@@ -980,6 +1008,152 @@ __global__ __launch_bounds__(64) void stream_cut_ctr_kernel(bpp_stream s, Stream
 // An unsorted box as the cut kernel leaves it (fields of w.fb bits) -> x | y << 8 | z << 16 | base height << 24.
 __device__ __forceinline__ uint32_t cut_box_bytes(uint32_t v, int fb) {
     return fb == 8 ? v : ((v & 15u) | ((v & 0xf0u) << 4) | ((v & 0xf00u) << 8) | ((v & 0xf000u) << 12));
+}
+
+// ======================================================================================================================
+// BPP_STREAM_RNG_COUNTER, rows pipeline (round 5): scan / cut_rows.  The counter generator keys every SEQUENCE separately
+// (seed0, stream id, episode), so the unit of work is a ring ROW, not a bin: one lane per row the scan listed, and the
+// lane that cut a sequence also ranks it -- the boxes wait in an LDS column of the lane instead of the row, a counting
+// sort by base height (depart_box, mdCreator.py:137-138: stable) over per-lane level counters in LDS puts them into the
+// row in their final order, key stripped, and leaves the look-ahead copies of the first two items in the two rows before
+// (what the sort kernel did from a cold read of the row, a hundred microseconds later).  The terminator padding behind the
+// items is written by the whole wave, one row after the other, in full lines.
+// A lane whose lists or whose staging column would overflow (capacities chosen so that it happens to one sequence in
+// thousands) stops, and is served again once the others are done: alone, with the whole wave's LDS as its lists and
+// staging area (entries at stride 1), which holds any sequence the geometry allows.
+// ======================================================================================================================
+__host__ __device__ inline int stream_rows_stage_cap(int W, int L, int H, int lo, int hi, int maxn) {
+    // twice the typical length of a sequence (bin volume over the volume of a box of mean sides), at least 16, a multiple of 8
+    const int mid2 = lo + hi;                   // 2 * mean side
+    const long typical = (long)W * L * H * 8 / ((long)mid2 * mid2 * mid2);
+    long c = (2 * typical + 7) / 8 * 8;
+    c = c < 16 ? 16 : c;
+    return (int)(c < maxn ? c : maxn);
+}
+// LDS entries of the lists and staging columns of a wave; the lane that is served alone needs 3 (maxn + 2) + 2 of them
+__host__ __device__ inline size_t stream_rows_lds_entries(int cap, int stage) { return ((size_t)(2 * cap + 1) + (size_t)(stage + 1)) * 64; }
+__host__ __device__ inline size_t stream_rows_lds_bytes(int cap, int stage, int fb, int H) {
+    return (stream_rows_lds_entries(cap, stage) * (fb == 4 ? 2 : 4) + 15) / 16 * 16 + (size_t)((H + 2) / 2) * 64 * 4;
+}
+
+// Sequence `ep` of stream `sid` for every lane with `active` set: cut (lists in `col`, finished boxes into `stage`), rank
+// by base height (`cnt`: the lane's level counters, see level_count), place into ring row `ep` of bin `bin` with the
+// look-ahead copies.  Returns the number of boxes; gave_up: a list or the staging column was full -- nothing written.
+template <int FB, class Col>
+__device__ __forceinline__ int rows_cut_and_place(const bpp_stream &s, bool active, int bin, int ep, uint64_t sid, const Col col, const Col stage,
+                                                  uint32_t *cnt, int cap, int S, bool &gave_up) {
+    const int E = s.num_envs, T = s.pool_len, D = s.depth, H = s.H;
+    const uint32_t lo = (uint32_t)s.bound_lo, hi = (uint32_t)s.bound_hi;
+    const uint32_t whole = (uint32_t)s.W | ((uint32_t)s.L << FB) | ((uint32_t)s.H << (2 * FB));
+    const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    uint32_t *row = (uint32_t *)s.ring + ((size_t)(ep % D) * E + bin) * T + kRowHdr;
+    CtrLane c{whole, 0, 1, 0, 0, 0, row, CtrRng::key(s.seed0, sid, (uint32_t)ep)};
+    if (active) col.set(0u, whole);
+    const int NW = (H + 2) >> 1;                      // words of level counters: levels 0 .. H - 1 and the one for nothing
+    for (int l = 0; l < NW; ++l) cnt[l * 64] = 0u;
+    const EmitToStage<Col, FB> emit{stage, cnt, (uint32_t)S, (uint32_t)H};
+    const bool mine0 = active;
+    gave_up = false;
+    for (;;) {
+        const bool full = active && (c.tail_a + 2 > cap || c.tail_b + 1 > cap || c.nv + 2 > S);
+        gave_up = gave_up || full;
+        active = active && !full;
+        if (!__ballot(active)) break;
+        if (cut_visit_ctr<FB>(c, col, cap, active ? ~0u : 0u, lo, hi, emit) != 0u) active = false;
+    }
+    const bool mine = mine0 && !gave_up;
+    const int nv = mine ? c.nv : 0;
+    // stable counting sort of the lane's boxes by base height: the counts become first positions (four levels, then four
+    // boxes, at a time: the LDS round trips of a group overlap), then every box takes the next position of its level
+    uint32_t run = 0;
+    for (int l0 = 0; l0 < NW; l0 += 4) {
+        uint32_t n[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n[j] = cnt[min(l0 + j, NW - 1) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t even = n[j] & 0xffffu, odd = n[j] >> 16;
+            if (l0 + j < NW) cnt[(l0 + j) * 64] = run | ((run + even) << 16);
+            run += even + odd;
+        }
+    }
+    uint32_t first = term, second = term;             // the row's first two items: the look-ahead copies in the two rows before
+    for (int k0 = 0; __ballot(k0 < nv); k0 += 4) {
+        uint32_t b[4], dest[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = stage.get((uint32_t)min(k0 + j, S));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dest[j] = level_count(cnt, k0 + j < nv ? b[j] >> (3 * FB) : (uint32_t)H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = cut_box_bytes(b[j], FB) & 0x00ffffffu;
+            if (k0 + j < nv) {
+                row[dest[j]] = v;
+                first = dest[j] == 0u ? v : first;
+                second = dest[j] == 1u ? v : second;
+            }
+        }
+    }
+    if (mine) {
+        if (ep >= 1) ((uint32_t *)s.ring + ((size_t)((ep - 1) % D) * E + bin) * T)[0] = second;
+        if (ep >= 2) ((uint32_t *)s.ring + ((size_t)((ep - 2) % D) * E + bin) * T)[1] = first;
+    }
+    return nv;
+}
+
+template <int FB>
+__global__ __launch_bounds__(64) void stream_cut_rows_kernel(bpp_stream s, StreamWork w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using LT = typename ListCol<FB>::T;
+    const int lane = threadIdx.x;
+    const int E = s.num_envs, T = s.pool_len, D = s.depth, cap = w.cap, S = w.stage;
+    const int TI = T - kRowHdr;
+    uint32_t *cnt = (uint32_t *)smem + lane;          // level counters first, then the lists and the staging columns
+    LT *lists = (LT *)(smem + (size_t)((s.H + 2) / 2) * 64 * 4);
+    const ListCol<FB> col{lists + lane};
+    const ListCol<FB> stage{lists + (size_t)(2 * cap + 1) * 64 + lane};
+    // the same memory for a lane that is served alone: lists and staging column of maxn + 2 entries each, stride 1
+    const int capx = w.maxn + 2;
+    const ListCol<FB, 1> colx{lists};
+    const ListCol<FB, 1> stagex{lists + (size_t)(2 * capx + 1)};
+    const uint32_t term = (uint32_t)s.W | ((uint32_t)s.L << 8) | ((uint32_t)s.H << 16);
+    const int nrows = w.hdr[3];
+    for (int q0 = (int)blockIdx.x * 64; q0 < nrows; q0 += (int)gridDim.x * 64) {     // wave-uniform
+        const int q = q0 + lane;
+        const bool job = q < nrows;
+        const int64_t id = job ? w.rows[q] : 0;
+        const int bin = (int)(uint32_t)id, ep = (int)(id >> 32);
+        uint64_t sid = 0;
+        if (job) {
+            const uint32_t *rc = s.mt + (size_t)bin * kCtrRec;
+            sid = (uint64_t)rc[0] | ((uint64_t)rc[1] << 32);
+            if (ep + 1 == w.target[bin]) s.gen_next[bin] = ep + 1;       // the bin's newest row: its generator is now here
+        }
+        bool gave_up;
+        int nv = rows_cut_and_place<FB>(s, job, bin, ep, sid, col, stage, cnt, cap, S, gave_up);
+        uint64_t again = __ballot(gave_up);
+        while (again) {                               // rare: one lane at a time with all of the wave's LDS
+            const int r = __ffsll((unsigned long long)again) - 1;
+            again &= again - 1;
+            wave_sync();
+            bool never;
+            const int n2 = rows_cut_and_place<FB>(s, lane == r, bin, ep, sid, colx, stagex, cnt, capx, capx, never);
+            if (lane == r) nv = n2;
+            wave_sync();
+        }
+        // terminator padding: the wave, row by row
+        uint32_t *row = (uint32_t *)s.ring + ((size_t)(ep % D) * E + bin) * T + kRowHdr;
+        const uint32_t plo = (uint32_t)(uintptr_t)row, phi = (uint32_t)((uint64_t)(uintptr_t)row >> 32);
+        uint64_t todo = __ballot(job);
+        while (todo) {
+            const int r = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int nr = (int)__builtin_amdgcn_readlane((uint32_t)nv, r);
+            const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane(plo, r), rhi = (uint32_t)__builtin_amdgcn_readlane(phi, r);   // (the builtin returns int)
+            uint32_t *rr = (uint32_t *)(uintptr_t)((uint64_t)rlo | ((uint64_t)rhi << 32));
+            for (int k = nr + lane; k < TI; k += 64) rr[k] = term;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void stream_sort_kernel(bpp_stream s, StreamWork w) {

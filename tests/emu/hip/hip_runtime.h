@@ -161,7 +161,7 @@ static inline T shfl_xor(T v, int m, int width, int line) {
 // returns a signed int like the real builtin (so that a missing cast sign-extends here as it does on the GPU)
 #define __builtin_amdgcn_readfirstlane(v) \
     ((int)(uint32_t)emu::rendezvous(emu::K_WAVE, emu::OP_FIRST, __LINE__, (uint64_t)(uint32_t)(v), 0))
-#define __builtin_amdgcn_readlane(v, l) (emu::shfl((uint32_t)(v), (int)(l), __LINE__))
+#define __builtin_amdgcn_readlane(v, l) ((int)emu::shfl((uint32_t)(v), (int)(l), __LINE__))   // int, like the compiler builtin: widening it sign-extends
 #define __shfl(v, src, width) emu::shfl_idx((v), (src), (width), __LINE__)
 #define __shfl_up(v, d, width) emu::shfl_up((v), (d), (width), __LINE__)
 #define __shfl_down(v, d, width) emu::shfl_down((v), (d), (width), __LINE__)
@@ -231,6 +231,11 @@ static inline float atomicAdd(float *p, float v) {
 }
 static inline int atomicAdd(int *p, int v) {
     const int o = *p;
+    *p = o + v;
+    return o;
+}
+static inline unsigned atomicAdd(unsigned *p, unsigned v) {
+    const unsigned o = *p;
     *p = o + v;
     return o;
 }

@@ -113,6 +113,12 @@ def test_counter_generator_words_are_uncorrelated_across_bins_episodes_and_draws
         assert abs(np.bincount((a >> np.uint64(31)).astype(int), minlength=2)[1] / N - 0.5) < 4.5 * 0.5 / np.sqrt(N), name
 
 
+# which refill serves lock-step t (the stream_legacy knob): 0 = the default pipeline (counter generator: rows), 1 = the plain
+# one-lane-per-bin kernel, 2 = scan / cut per bin / sort, 3 = rows with most rows going through the redo kernel
+PATTERNS = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "plain": lambda t: 1, "bins": lambda t: 2, "redo": lambda t: 3,
+            "all four": lambda t: (0, 3, 2, 1)[t % 4]}
+
+
 @pytest.mark.parametrize("size,rot,E,steps,depth,refill,native", [((10, 10, 10), False, 70, 60, 8, 5, False),
                                                                   ((10, 10, 10), True, 40, 64, 20, 8, True),
                                                                   ((20, 20, 20), False, 5, 30, 9, 3, True),
@@ -126,9 +132,12 @@ def test_emulated_counter_supply_matches_oracle_and_python(emu, oracle, size, ro
     ((10, 10, 10), 130, 8, 40, "fast"), ((10, 10, 10), 130, 8, 40, "alternate"), ((10, 10, 10), 70, 6, 60, "plain"),
     ((20, 20, 20), 9, 5, 12, "alternate"), ((8, 12, 9), 40, 6, 30, "fast"),
     ((30, 30, 18), 2, 4, 2, "fast"),             # pending lists beyond the LDS part
+    ((10, 10, 10), 130, 8, 40, "bins"),          # round 4's scan / cut per bin / sort
+    ((10, 10, 10), 130, 8, 40, "redo"),          # rows pipeline with capacities that send most rows to its redo kernel
+    ((12, 12, 12), 70, 7, 30, "redo"), ((10, 10, 10), 200, 9, 60, "all four"), ((15, 15, 15), 20, 6, 16, "fast"),
 ])
 def test_emulated_counter_fast_and_plain_refill_interchangeable(emu, oracle, size, E, depth, steps, pattern):
-    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "plain": lambda t: 1}[pattern]
+    pat = PATTERNS[pattern]
     knob_check(lambda sz, n, base, spec: EmuKnobEnv(emu, sz, n, base, spec), oracle, lambda **kw: emu.set_knobs(**kw), size, E, depth,
                steps, pat, gen="counter")
 
@@ -213,10 +222,12 @@ def test_gpu_counter_supply_matches_oracle_and_python(oracle, size, rot, E, step
 @pytest.mark.parametrize("size,E,depth,steps,pattern", [
     ((10, 10, 10), 5000, 8, 60, "fast"), ((10, 10, 10), 5000, 8, 60, "alternate"), ((10, 10, 10), 3000, 6, 120, "plain"),
     ((20, 20, 20), 130, 5, 20, "alternate"), ((8, 12, 9), 300, 6, 40, "fast"), ((30, 30, 18), 70, 4, 3, "fast"),
+    ((10, 10, 10), 5000, 8, 60, "bins"), ((10, 10, 10), 5000, 8, 60, "redo"), ((12, 12, 12), 700, 7, 40, "redo"),
+    ((10, 10, 10), 4000, 9, 80, "all four"), ((15, 15, 15), 300, 6, 24, "fast"), ((10, 10, 10), 70000, 8, 20, "fast"),
 ])
 def test_gpu_counter_fast_and_plain_refill_interchangeable(oracle, size, E, depth, steps, pattern):
     import bpp_amd
-    pat = {"fast": lambda t: 0, "alternate": lambda t: t % 2, "plain": lambda t: 1}[pattern]
+    pat = PATTERNS[pattern]
     knob_check(GpuKnobEnv, oracle, lambda **kw: bpp_amd._lib.set_knobs(**kw), size, E, depth, steps, pat, gen="counter")
 
 
