@@ -40,6 +40,7 @@ python tools/bench_acc_reduce.py > $O/acc_reduce.json 2>> $O/bench.err
 for cfg in "mt19937_d32_r14:" "mt19937_d64_r30:--stream-depth 64 --stream-refill 30" "counter_d32_r14:--stream-rng counter" \
            "counter_d64_r30:--stream-rng counter --stream-depth 64 --stream-refill 30" \
            "counter_rot_d64_r30:--stream-rng counter --rotation --stream-depth 64 --stream-refill 30" \
+           "counter_d128_r60:--stream-rng counter --stream-depth 128 --stream-refill 60" \
            "mt19937_20_d32_r14:--size 20 20 20 --envs 32768" "counter_20_d32_r14:--stream-rng counter --size 20 20 20 --envs 32768"; do
   name=${cfg%%:*}; args=${cfg#*:}
   python bench.py --no-cpu-baseline --stream --gpu-seconds 1.5 $args > $O/bench_stream_$name.json 2>> $O/bench.err
