@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 14
+#define BPP_ABI_VERSION 15
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -360,6 +360,15 @@ int bpp_fetch_to_host(const void *device_src, void *host_dst, int64_t nbytes, vo
 /* hipStreamSynchronize(stream): what step_wait() needs when bpp_step wrote reward / done into host memory itself
  * (bpp_step_out.host_reward / host_done). */
 int bpp_wait(void *stream);
+/* The same wait without the runtime's synchronisation call (v15): bpp_mark enqueues "store `value` into the 32-bit word at
+ * `host_flag` (page-locked host memory the device can write) once everything enqueued on `stream` before is complete" -- a
+ * stream memory operation, or a one-thread kernel where the runtime offers none --, bpp_wait_mark spins on that word (and asks
+ * the stream for errors now and then; a stream that reports completion without the word having arrived is synchronised and the
+ * word read once more).  BppVecEnv.step_async() marks its staging buffer with the step's serial number behind the step kernel
+ * (and the eager gather), step_wait() waits for it: the host sees reward / done a few microseconds after the kernel's last
+ * store instead of after a signal round trip.  Use a value the word does not hold yet. */
+int bpp_mark(void *host_flag, uint32_t value, void *stream);
+int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream);
 
 /* `infos` of the bins that finished in a lock-step (main.py:159-162 reads infos[i]['episode']['r'] and infos[i]['ratio']
  * of exactly those; bench/monitor.py:64-75, bin3D.py:111).  `n` = the number of finished bins the caller counted in ITS

@@ -1975,6 +1975,9 @@ __device__ __forceinline__ int nonzero_bytes(uint32_t v) {
     const uint32_t t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v;    // bit 7 of every byte that is not zero
     return __popc(t & 0x80808080u);
 }
+// bpp_mark where the runtime has no stream memory operation: one thread, one system-scope store
+__global__ void mark_kernel(uint32_t *flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 __global__ __launch_bounds__(kGatherThreads) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
                                                                           const int32_t *ep_len, const int32_t *counter, int E,
                                                                           unsigned char *out, int n, int chunk) {
@@ -2731,6 +2734,38 @@ int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double 
 int bpp_wait(void *stream) {
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
+}
+
+int bpp_mark(void *host_flag, uint32_t value, void *stream) {
+    if (!host_flag || ((uintptr_t)host_flag & 3u)) return fail(BPP_E_BADARG, "bpp_mark: NULL / misaligned flag");
+    static std::atomic<int> use_kernel{0};      // the stream memory operation failed once in this process: marker kernel from then on
+    if (!use_kernel.load(std::memory_order_relaxed)) {
+        if (hipStreamWriteValue32((hipStream_t)stream, host_flag, value, 0) == hipSuccess) return 0;
+        (void)hipGetLastError();
+        use_kernel.store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t *)host_flag, value);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream) {
+    if (!host_flag) return fail(BPP_E_BADARG, "bpp_wait_mark: NULL flag");
+    const uint32_t *f = (const uint32_t *)host_flag;
+    for (uint32_t spins = 1;; ++spins) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == value) return 0;
+        if ((spins & 0xfffu) == 0) {            // every few microseconds: is the stream still alive?
+            hipError_t q = hipStreamQuery((hipStream_t)stream);
+            if (q == hipSuccess) {              // all done and the word not seen yet: synchronise, look once more
+                q = hipStreamSynchronize((hipStream_t)stream);
+                if (q != hipSuccess) return hip_fail(q, "hipStreamSynchronize");
+                if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == value) return 0;
+                return fail(BPP_E_BADARG, "bpp_wait_mark: the stream is idle and the flag does not hold the value (no bpp_mark enqueued?)");
+            }
+            if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery");
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,

@@ -411,12 +411,14 @@ class BppVecEnv(object):
         self._last_stream = None
         self._serial = 0           # lock-steps issued (LazyInfos: which step the shared output buffers belong to)
         self._pending = None
+        self._mark = 0             # serial number of the last bpp_mark (never 0: a cleared completion word)
         self._tstart = time.time()
         self.monitor = None        # MonitorCsv (make_vec_envs with a log_dir): step_wait() appends the finished episodes' rows
         self._side = None          # bpp_side (rollout_uniform in streaming mode): created on first use
         self.closed = False
 
     MAX_STAGING = 16     # page-locked host buffers (29 B per bin each) handed out at the same time, at most
+    spin_wait = True     # step_wait() spins on the step's completion word (bpp_mark / bpp_wait_mark); False: hipStreamSynchronize
 
     # ------------------------------------------------------------------ buffers
     def _layout(self):
@@ -538,6 +540,10 @@ class BppVecEnv(object):
     def _stage_bytes(self):
         """A staging buffer = the per-bin scalar block (29 B per bin; the kernel mirrors its first 5: reward, done) and, with
         eager_infos, the compacted records of the finished bins (28 B per bin of room; a step fills the first ~11 % of each array)."""
+        return self._mark_offset() + 8
+
+    def _mark_offset(self):
+        """Byte offset of the step's completion word (bpp_mark / bpp_wait_mark) in a staging buffer: behind everything else."""
         return self._fin_offset() + ((32 + 28 * self.E + 4 + 7) // 8 * 8 if self.eager_infos else 0)
 
     def _gather_finished(self, res, n):
@@ -743,19 +749,26 @@ class BppVecEnv(object):
                                               base + lay["counter"][0], self.E, None, host.ctypes.data + self._fin_offset(), -1, self._last_stream)
             if rc:
                 _lib.check(rc)
-        self._pending = (res, host, self._last_stream)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
+        mark = None
+        if host is not None and self.spin_wait:   # the step's serial number lands in the buffer when everything above is complete: step_wait() spins on it
+            mark = self._mark = (self._mark + 1) & 0xffffffff or 1       # (never a value the buffer's word still holds from an earlier step)
+            rc = self.lib.bpp_mark(host.ctypes.data + self._mark_offset(), self._mark, self._last_stream)
+            if rc:
+                _lib.check(rc)
+        self._pending = (res, host, self._last_stream, mark)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
 
     def step_wait(self):
         """(obs, reward, done, infos) with the reference's types (acktr/envs.py:189-193)."""
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
-        (r, host, stream), self._pending = self._pending, None
+        (r, host, stream, mark), self._pending = self._pending, None
         fin = None
         if host is None:
             rew, done = r.host_reward_done(stream)          # one 5-byte-per-bin copy + stream synchronise
             done = done.view(np.bool_)
         else:
-            rc = self.lib.bpp_wait(stream)   # the kernel wrote reward / done into `host` itself
+            # the kernel wrote reward / done into `host` itself: wait for the step's completion word (or synchronise the stream)
+            rc = self.lib.bpp_wait_mark(host.ctypes.data + self._mark_offset(), mark, stream) if mark is not None else self.lib.bpp_wait(stream)
             if rc:
                 _lib.check(rc)
             offs, E = self._layout()[2], self.E

@@ -509,6 +509,19 @@ int bpp_wait(void *stream) {
     return 0;
 }
 
+int bpp_mark(void *host_flag, uint32_t value, void *stream) {       /* no queue here: everything before is complete */
+    (void)stream;
+    if (!host_flag) return fail(BPP_E_BADARG, "bpp_mark: NULL flag");
+    *(uint32_t *)host_flag = value;
+    return 0;
+}
+
+int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream) {
+    (void)stream;
+    if (!host_flag) return fail(BPP_E_BADARG, "bpp_wait_mark: NULL flag");
+    return *(const uint32_t *)host_flag == value ? 0 : fail(BPP_E_BADARG, "bpp_wait_mark: the flag does not hold the value (no bpp_mark?)");
+}
+
 int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed, uint64_t step, uint32_t eps_q24,
                          void *stream) {
     (void)stream;

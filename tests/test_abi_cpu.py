@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_limits(lib):
-    assert lib.bpp_abi_version() == 14
+    assert lib.bpp_abi_version() == 15
     assert _lib.limits() == (1024, 255)
 
 
@@ -98,3 +98,17 @@ def test_bench_touches_the_reference_only_inside_the_cpu_baseline_leg():
     assert "/root/reference" not in txt.replace("/root/reference is never read", "")
     body = txt[txt.index("def main():"):]
     assert "ref_shims" not in body and "ref_baseline" not in body and "from oracle" not in body
+
+
+def test_mark_and_wait_mark_on_the_oracle_library(oracle):
+    """bpp_mark / bpp_wait_mark (ABI v15): the completion word a step leaves behind in host memory; on the CPU libraries
+    everything enqueued is complete at once."""
+    import ctypes
+    lib = oracle.lib()
+    lib.bpp_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    lib.bpp_wait_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    word = np.zeros(2, dtype=np.uint32)
+    assert lib.bpp_wait_mark(word.ctypes.data, 7, None) != 0         # nothing marked yet
+    assert lib.bpp_mark(word.ctypes.data, 7, None) == 0 and word[0] == 7 and word[1] == 0
+    assert lib.bpp_wait_mark(word.ctypes.data, 7, None) == 0
+    assert lib.bpp_mark(None, 1, None) != 0 and lib.bpp_wait_mark(None, 1, None) != 0

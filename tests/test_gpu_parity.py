@@ -424,6 +424,44 @@ def test_gpu_dropin_finished_infos_through_the_native_gather(bpp, oracle):
     assert float(env2.ep_acc.abs().sum()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("eager", [False, True])
+def test_gpu_dropin_step_waits_on_its_completion_word(bpp, oracle, eager):
+    """step_wait() spins on the word bpp_mark leaves in the step's page-locked buffer behind the step kernel (and the eager
+    gather) instead of synchronising the stream (ABI v15): same reward / done / infos as the oracle and as an env that
+    synchronises, step after step; a word nobody marked is reported, not waited for."""
+    import ctypes
+    import torch
+    size, E = (10, 10, 10), 20000
+    pool = bpp.sequences.cut2_pool(size, 512, seed=5)
+    envs = [bpp.BppVecEnv(E, size, pool=pool, eager_infos=eager) for _ in range(2)]
+    envs[1].spin_wait = False
+    ref = oracle.OracleEnv(pool, size, False, E)
+    for e in envs:
+        e.reset()
+    ref.reset()
+    a = envs[0].sample_feasible(seed=4, step=0)
+    for t in range(40):
+        a_np = a.cpu().numpy().copy()
+        o = ref.step(a_np)
+        outs = [e.step(torch.from_numpy(a_np).to(e.device)) for e in envs]
+        for obs, reward, done, infos in outs:
+            np.testing.assert_array_equal(done, o["done"].astype(bool))
+            np.testing.assert_array_equal(reward.numpy()[:, 0], o["reward"])
+            ep = infos.episodes()
+            d = np.flatnonzero(o["done"])
+            np.testing.assert_array_equal(ep["bins"], d)
+            np.testing.assert_array_equal(ep["ratio"], o["ratio"][d])
+        assert envs[0]._mark == t + 1 and envs[1]._mark == 0
+        a = torch.from_numpy(oracle.sample_feasible(o["mask"], 4, t + 1)).to(envs[0].device)
+    lib = bpp._lib.lib()
+    word = torch.zeros(2, dtype=torch.int32).pin_memory()
+    torch.cuda.synchronize()
+    assert lib.bpp_wait_mark(word.data_ptr(), 5, envs[0]._stream_ptr()) != 0 and b"flag" in lib.bpp_last_error()
+    assert lib.bpp_mark(word.data_ptr(), 5, envs[0]._stream_ptr()) == 0
+    assert lib.bpp_wait_mark(word.data_ptr(), 5, envs[0]._stream_ptr()) == 0 and int(word[0]) == 5 and int(word[1]) == 0
+
+
 @pytest.mark.parametrize("size,rot,E", [((10, 10, 10), False, 4099), ((10, 10, 10), True, 1000), ((20, 20, 20), False, 301),
                                          ((20, 20, 10), True, 130), ((7, 13, 8), True, 97)])
 def test_gpu_fused_next_action_equals_standalone_sampler(bpp, oracle, kernel_path, size, rot, E):

@@ -23,14 +23,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--quick", action="store_true", help="only tensors / step / step+episodes_arrays")
     args = ap.parse_args()
     import torch
     import bpp_amd
     size = (10, 10, 10)
     pool = bpp_amd.sequences.cut2_pool(size, 8192, seed=0)
     out = {"envs": args.envs, "steps": args.steps}
-    for fresh, eager in ((False, False), (False, True), (True, True)):
+    # (fresh_outputs, eager_infos, spin_wait): the last one False = step_wait() synchronises the stream (rounds 3 - 4) instead of
+    # spinning on the step's completion word
+    for fresh, eager, spin in ((False, False, True), (False, True, True), (True, True, True), (False, False, False), (False, True, False)):
         env = bpp_amd.BppVecEnv(args.envs, size, pool=pool, fresh_outputs=fresh, eager_infos=eager)
+        env.spin_wait = spin
         env.reset()
         a = env.sample_feasible(seed=1, step=0)
         host = {"async": 0.0, "wait": 0.0, "n": 0}
@@ -77,6 +81,8 @@ def main():
 
         kinds = ["tensors", "step", "step+sampler_launch", "step+one_finished_info", "step+episodes_arrays", "step+scan_episodes_arrays_like_main_py", "step+running_info",
                  "step+scan_finished_like_main_py"]
+        if args.quick or not spin:
+            kinds = ["tensors", "step", "step+episodes_arrays"]
         for kind in kinds:
             n = args.steps if kind != "step+scan_finished_like_main_py" else max(10, args.steps // 10)
             run(kind, 30 if n > 30 else 3, 0)
@@ -86,7 +92,7 @@ def main():
             run(kind, n, 30)
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / n * 1e6
-            tag = ("_fresh_outputs" if fresh else "") + ("_eager_infos" if eager else "")
+            tag = ("_fresh_outputs" if fresh else "") + ("_eager_infos" if eager else "") + ("" if spin else "_stream_synchronise")
             key = "%s%s_us_per_lockstep" % (kind, tag)
             out[key] = round(us, 1)
             if kind == "step":
@@ -95,7 +101,7 @@ def main():
         del env
         torch.cuda.empty_cache()
     out["note"] = ("tensors / step: ONE launch per lock-step (the step kernel draws the next action itself); step = step kernel (also "
-                   "writing reward + done, 5 bytes per bin, into page-locked host memory) + stream sync; +sampler_launch: a separate "
+                   "writing reward + done, 5 bytes per bin, into page-locked host memory) + a completion word the host spins on (bpp_mark / bpp_wait_mark; '_stream_synchronise': hipStreamSynchronize instead); +sampler_launch: a separate "
                    "bpp_sample_feasible launch per step as in round 3; +one_finished_info / +episodes_arrays: the finished bins' (r, l, ratio, "
                    "counter): without eager_infos bpp_gather_finished when somebody looks (one launch + a second sync); with eager_infos "
                    "(make_vec_envs' setting) the compaction is enqueued behind every step kernel and step_wait()'s one sync covers it; "
