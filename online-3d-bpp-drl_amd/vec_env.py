@@ -529,6 +529,7 @@ class BppVecEnv(object):
             return None if mapped else np.empty((n,), dtype=np.uint8)    # (a kernel cannot write into pageable memory)
         t = torch.empty((n,), dtype=torch.uint8).pin_memory()
         a = t.numpy()
+        a[n - 8:] = 0                           # the completion word (bpp_mark): no step's serial number yet
         pool.append((t, a))
         return a
 
