@@ -135,6 +135,7 @@ def test_emulated_counter_supply_matches_oracle_and_python(emu, oracle, size, ro
     ((10, 10, 10), 130, 8, 40, "bins"),          # round 4's scan / cut per bin / sort
     ((10, 10, 10), 130, 8, 40, "redo"),          # rows pipeline with capacities that send most rows to its redo kernel
     ((12, 12, 12), 70, 7, 30, "redo"), ((10, 10, 10), 200, 9, 60, "all four"), ((15, 15, 15), 20, 6, 16, "fast"),
+    ((16, 4, 4), 70, 6, 30, "fast"), ((16, 4, 4), 70, 6, 30, "redo"),      # a side >= 16: 8-bit box fields (the rows kernel's other instantiation)
 ])
 def test_emulated_counter_fast_and_plain_refill_interchangeable(emu, oracle, size, E, depth, steps, pattern):
     pat = PATTERNS[pattern]
@@ -224,6 +225,7 @@ def test_gpu_counter_supply_matches_oracle_and_python(oracle, size, rot, E, step
     ((20, 20, 20), 130, 5, 20, "alternate"), ((8, 12, 9), 300, 6, 40, "fast"), ((30, 30, 18), 70, 4, 3, "fast"),
     ((10, 10, 10), 5000, 8, 60, "bins"), ((10, 10, 10), 5000, 8, 60, "redo"), ((12, 12, 12), 700, 7, 40, "redo"),
     ((10, 10, 10), 4000, 9, 80, "all four"), ((15, 15, 15), 300, 6, 24, "fast"), ((10, 10, 10), 70000, 8, 20, "fast"),
+    ((16, 4, 4), 900, 6, 40, "fast"), ((16, 4, 4), 900, 6, 40, "redo"),
 ])
 def test_gpu_counter_fast_and_plain_refill_interchangeable(oracle, size, E, depth, steps, pattern):
     import bpp_amd
