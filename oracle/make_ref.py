@@ -12,7 +12,8 @@ working tree.  `__graft_entry__.build()` runs this recipe whenever /root/referen
 
 What is copied: exactly the files Python loads when the modules below are imported and exercised (found by tracing
 sys.modules, not by a hand-kept list), byte for byte, at their original relative paths, plus dataset/cut_2.pt (the
-reference's CUT-2 test set, played through LoadBoxCreator by the parity suite).  MANIFEST.json records the sha256 of
+reference's CUT-2 test set, played through LoadBoxCreator by the parity suite) and the two pretrained checkpoints for
+it (pretrained_models/default_cut_2.pt, rotation_cut_2.pt: the competent policies of the deep parity cases).  MANIFEST.json records the sha256 of
 every file and of its source; README.txt states provenance.  Nothing under oracle/_ref/ is ever imported by the
 product (tests/test_abi_cpu.py::test_product_never_imports_the_oracle covers `_ref` too).
 """
@@ -34,7 +35,9 @@ ENTRY = ["envs.bpp0", "envs.bpp0.bin3D", "envs.bpp0.space", "envs.bpp0.binCreato
          "envs.bpp0.mdCreator", "acktr.envs", "acktr.utils", "acktr.model", "acktr.storage", "acktr.algo",
          "acktr.distributions", "baselines.bench", "baselines.bench.monitor", "baselines.common.vec_env",
          "baselines.common.vec_env.shmem_vec_env", "baselines.common.vec_env.dummy_vec_env"]
-DATA = ["dataset/cut_2.pt"]
+# data files: the reference's CUT-2 test set and the two checkpoints main.py:26-29 -> unified_test.py:29-67 evaluate on it
+# (acktr/model_loader.py:19-35 loads them; the parity suite plays them greedily through the reference's own Policy.act)
+DATA = ["dataset/cut_2.pt", "pretrained_models/default_cut_2.pt", "pretrained_models/rotation_cut_2.pt"]
 
 TRACE = r"""
 import json, os, sys

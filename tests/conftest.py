@@ -27,9 +27,28 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
+# rollout_deep_* / rollout_pretrained_* (round 6): recorded from the reference under a COMPETENT policy -- the lowest-top
+# heuristic of oracle/policies.py and the reference's own pretrained checkpoints played greedily (make_golden.py --deep)
+DEEP_CASES = ["rollout_deep_cut2_10", "rollout_deep_cut2_10_rot", "rollout_deep_cut2_20",
+              "rollout_pretrained_cut2_10", "rollout_pretrained_cut2_10_rot"]
 ROLLOUT_CASES = ["rollout_cut2_10", "rollout_cut2_10_rot", "rollout_cut2_20", "rollout_rs_10",
-                 "rollout_wide_8x12x9_rot", "rollout_short_5x4x6"]
+                 "rollout_wide_8x12x9_rot", "rollout_short_5x4x6"] + DEEP_CASES
 MASK_CASES = ["masks_10", "masks_20", "masks_7x13x8"]
+
+
+def depth_profile(g):
+    """(share of recorded env-steps on bins that already hold >= 20 boxes, number of COMPLETELY packed bins -- final ratio
+    1.0 with the terminator as the current item --, mean final ratio) of a recording in the golden format."""
+    import numpy as np
+    W, L, H = (int(v) for v in g["size"])
+    A = W * L
+    d = g["done"].astype(bool)
+    full = 0
+    for t, e in zip(*np.nonzero(d & (g["ratio"] == 1.0))):
+        prev = g["obs0"][e] if t == 0 else g["obs"][t - 1][e]
+        assert (int(prev[A]), int(prev[2 * A]), int(prev[3 * A])) == (W, L, H)    # what failed was the terminator
+        full += 1
+    return float((g["counter"] >= 20).mean()), full, float(g["ratio"][d].mean())
 
 
 @pytest.fixture(scope="session")

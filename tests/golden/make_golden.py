@@ -97,7 +97,67 @@ def exact(a, dtype):
     return b
 
 
-def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=None, env_ids=None, env_total=None):
+def choose_actions(policy, rng, obs, mask, size, rotation, p_random, allow_past_area):
+    """The recorded rollouts' action source.  "uniform" (every fixture up to round 5): a uniform draw among the mask's
+    feasible entries, with probability p_random any index (some of them out of range).  "lowest_top"
+    (oracle/policies.py: lowest resulting top, then smoothest surface, then lowest index -- deep episodes, full bins),
+    with probability p_random a uniform feasible entry instead (bins that play the same pool row drift apart).  A
+    callable: the reference's own pretrained Policy (pretrained_policy below), greedy."""
+    E, M = mask.shape
+    A = size[0] * size[1]
+    if policy == "uniform":
+        a = np.zeros(E, np.int64)
+        for e in range(E):
+            if rng.rand() < p_random:
+                a[e] = rng.randint(0, M + 2) - 1 if rng.rand() < 0.1 else rng.randint(0, M)
+                if not allow_past_area:
+                    a[e] = min(max(a[e], -1), A)   # reference asserts for idx > A without rotation
+            else:
+                a[e] = rng.choice(np.flatnonzero(mask[e]))
+        return a
+    if policy == "lowest_top":
+        from oracle.policies import lowest_top_actions
+        a = lowest_top_actions(obs.numpy(), mask, size, rotation)
+    else:
+        a = policy(obs, mask)
+    for e in range(E):
+        if rng.rand() < p_random:
+            a[e] = rng.choice(np.flatnonzero(mask[e]))
+    return a
+
+
+def pretrained_policy(path, size, rotation):
+    """The reference's checkpoint loaded the way main.py:66-76 / acktr/model_loader.py:19-35 load it (`module.` /
+    `add_bias.` / `_bias` key rewrites, trailing-1 squeeze) into the reference's own acktr.model.Policy; returns
+    f(obs [E, 4A] tensor, mask [E, M] array) -> int64 [E]: Policy.act(..., deterministic=True) with the true mask
+    (main.py:150-153 with dist.mode()).  Runs on the CPU; the actions are RECORDED, so no cross-machine float claim."""
+    import types
+    from acktr.model import Policy
+    import bpp_amd
+    A = size[0] * size[1]
+    args = types.SimpleNamespace(channel=4, container_size=tuple(size), pallet_size=size[0], enable_rotation=bool(rotation),
+                                 hidden_size=256, device="cpu")
+    model_pretrained, ob_rms = torch.load(path, map_location="cpu", weights_only=False)
+    assert ob_rms is None
+    ac = Policy((4 * A,), bpp_amd.spaces.Discrete(A * (1 + int(bool(rotation)))),
+                base_kwargs={'recurrent': False, 'hidden_size': args.hidden_size, 'args': args})
+    load_dict = {k.replace('module.', ''): v for k, v in model_pretrained.items()}
+    load_dict = {k.replace('add_bias.', ''): v for k, v in load_dict.items()}
+    load_dict = {k.replace('_bias', 'bias'): v for k, v in load_dict.items()}
+    for k, v in load_dict.items():
+        if len(v.size()) <= 3:
+            load_dict[k] = v.squeeze(dim=-1)
+    ac.load_state_dict(load_dict)
+    ac.eval()
+
+    def act(obs, mask):
+        with torch.no_grad():
+            _, action, _, _ = ac.act(obs, None, None, torch.FloatTensor(mask), deterministic=True)
+        return action.reshape(-1).numpy().astype(np.int64)
+    return act
+
+
+def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=None, env_ids=None, env_total=None, policy="uniform"):
     """One recorded rollout of the reference stack -> <out_dir or tests/golden>/<name>.npz.  env_ids / env_total: the E
     recorded envs are the global bins env_ids of a job of env_total bins (stored in the file as `env_ids`, `env_total`)."""
     W, L, H = size
@@ -110,14 +170,7 @@ def rollout_case(name, pool, size, rotation, E, steps, seed, p_random, out_dir=N
     rec = dict(obs0=exact(obs.numpy(), np.uint8), mask0=exact(mask, np.uint8), smask0=exact(space_masks(dummy), np.uint8))
     acts, obss, masks, smasks, rews, rews64, dones, counters, ratios, ep_r, ep_l, ep_r_raw = ([] for _ in range(12))
     for _ in range(steps):
-        a = np.zeros(E, np.int64)
-        for e in range(E):
-            if rng.rand() < p_random:
-                a[e] = rng.randint(0, M + 2) - 1 if rng.rand() < 0.1 else rng.randint(0, M)
-                if not rotation:
-                    a[e] = min(max(a[e], -1), A)   # reference asserts for idx > A without rotation
-            else:
-                a[e] = rng.choice(np.flatnonzero(mask[e]))
+        a = choose_actions(policy, rng, obs, mask, size, rotation, p_random, bool(rotation))
         obs, reward, done, infos = venv.step(torch.from_numpy(a).unsqueeze(1))
         mask = loop_masks(obs, size, rotation)
         acts.append(a)
@@ -263,6 +316,27 @@ def main():
     mask_case("masks_10", (10, 10, 10), 400, 11, 1, 7)
     mask_case("masks_20", (20, 20, 20), 120, 12, 1, 9)
     mask_case("masks_7x13x8", (7, 13, 8), 200, 13, 1, 8)
+    deep()
+
+
+def deep():
+    """Round 6: fixtures whose states a COMPETENT policy reaches -- `python make_golden.py --deep` makes
+    only these.  rollout_deep_*: the lowest-top heuristic (oracle/policies.py) with 2 % uniform-feasible noise on rows of
+    reference-generated CUT-2 sequences (MDlayerBoxCreator, 10x10x10 and 20x20x20); rollout_pretrained_*: the
+    reference's own checkpoints (pretrained_models/default_cut_2.pt, rotation_cut_2.pt) played greedily through the
+    reference's Policy.act with the true mask on dataset/cut_2.pt through LoadBoxCreator (main.py:26-29 ->
+    unified_test.py:29-67 evaluate these checkpoints on this file)."""
+    seq10 = cut2_reference_sequences((10, 10, 10), 192, seed0=300)       # MDlayerBoxCreator under random.seed(300 + k)
+    gen10 = pad_pool(seq10, max(len(s) for s in seq10) + 1, (10, 10, 10))
+    rollout_case("rollout_deep_cut2_10", gen10[:96], (10, 10, 10), False, E=8, steps=240, seed=21, p_random=0.02, policy="lowest_top")
+    rollout_case("rollout_deep_cut2_10_rot", gen10[96:], (10, 10, 10), True, E=8, steps=240, seed=22, p_random=0.02, policy="lowest_top")
+    seq20 = cut2_reference_sequences((20, 20, 20), 12, seed0=200)
+    pool20 = pad_pool(seq20, max(len(s) for s in seq20) + 1, (20, 20, 20))
+    rollout_case("rollout_deep_cut2_20", pool20, (20, 20, 20), False, E=4, steps=420, seed=23, p_random=0.01, policy="lowest_top")
+    ds = os.path.join(ref_shims.REFERENCE_ROOT, "dataset", "cut_2.pt")
+    for name, ckpt, rot in (("rollout_pretrained_cut2_10", "default_cut_2.pt", False), ("rollout_pretrained_cut2_10_rot", "rotation_cut_2.pt", True)):
+        pol = pretrained_policy(os.path.join(ref_shims.REFERENCE_ROOT, "pretrained_models", ckpt), (10, 10, 10), rot)
+        dataset_case(name, ds, (10, 10, 10), E=8, steps=120, seed=24 + rot, p_random=0.0, out_dir=HERE, rotation=rot, policy=pol)
 
 
 def live_case(spec_json):
@@ -270,23 +344,30 @@ def live_case(spec_json):
     (BPP_REFERENCE_ROOT; the GPU suite points it at oracle/_ref/), written to spec["out_dir"] -- the same format as the
     committed fixtures, so the same checker replays it on the HIP path (tests/test_gpu_vs_live_reference.py).
     spec: name, out_dir, size, rotation, E, steps, seed, p_random and either pool (npz path) or dataset (a
-    reference dataset/*.pt played through the reference's own LoadBoxCreator, binCreator.py:42-72)."""
+    reference dataset/*.pt played through the reference's own LoadBoxCreator, binCreator.py:42-72); optional policy
+    ("uniform" | "lowest_top") or checkpoint (a reference pretrained_models/*.pt, played greedily)."""
     import json
     spec = json.loads(spec_json)
     size = tuple(spec["size"])
+    policy = spec.get("policy", "uniform")
+    if spec.get("checkpoint"):
+        policy = pretrained_policy(spec["checkpoint"], size, bool(spec["rotation"]))
     if spec.get("dataset"):
-        dataset_case(spec["name"], spec["dataset"], size, spec["E"], spec["steps"], spec["seed"], spec["p_random"], spec["out_dir"])
+        dataset_case(spec["name"], spec["dataset"], size, spec["E"], spec["steps"], spec["seed"], spec["p_random"], spec["out_dir"],
+                     rotation=bool(spec["rotation"]), policy=policy)
         return
     pool = np.load(spec["pool"])["pool"]
     rollout_case(spec["name"], pool, size, bool(spec["rotation"]), spec["E"], spec["steps"], spec["seed"], spec["p_random"],
-                 out_dir=spec["out_dir"], env_ids=spec.get("env_ids"), env_total=spec.get("env_total"))
+                 out_dir=spec["out_dir"], env_ids=spec.get("env_ids"), env_total=spec.get("env_total"), policy=policy)
 
 
-def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):
+def dataset_case(name, path, size, E, steps, seed, p_random, out_dir, rotation=False, policy="uniform"):
     """E reference envs built the way `--load-dataset` builds them -- PackingGame(test=True, data_name=path): the
     reference's LoadBoxCreator, unmodified -- whose creators start at trajectory index e (attribute set from outside;
     LoadBoxCreator.reset pre-increments, so episode k of env e plays trajectory e + k + 1).  Recorded like
-    rollout_case; `pool` in the file holds sequences.from_dataset's rows of the same file."""
+    rollout_case; `pool` in the file holds sequences.from_dataset's rows of the same file.  policy: "uniform",
+    "lowest_top" or a callable (pretrained_policy: the reference's own checkpoint, greedy, on its own test set -- the
+    states unified_test.py:29-67 / model_loader.py evaluate the paper's numbers on)."""
     import contextlib
     import io
     import bpp_amd
@@ -295,7 +376,7 @@ def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):
     def thunk(e):
         def _t():
             with contextlib.redirect_stdout(io.StringIO()):
-                env = PackingGame(container_size=size, test=True, data_name=path, enable_rotation=False)
+                env = PackingGame(container_size=size, test=True, data_name=path, enable_rotation=bool(rotation))
             assert isinstance(env.box_creator, LoadBoxCreator)
             env.box_creator.index = e
             return bench.Monitor(env, None, allow_early_resets=False)
@@ -306,14 +387,17 @@ def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):
     rng = np.random.RandomState(seed)
     A = size[0] * size[1]
     obs = venv.reset()
-    mask = loop_masks(obs, size, False)
+    mask = loop_masks(obs, size, rotation)
     rec = dict(obs0=exact(obs.numpy(), np.uint8), mask0=exact(mask, np.uint8), smask0=exact(space_masks(dummy), np.uint8))
     keys = ("actions", "obs", "mask", "smask", "reward", "done", "counter", "ratio", "ep_r", "ep_l", "ep_r_raw")
     cols = {k: [] for k in keys}
     for _ in range(steps):
-        a = np.array([rng.randint(0, A) if rng.rand() < p_random else rng.choice(np.flatnonzero(mask[e])) for e in range(E)], np.int64)
+        if policy == "uniform":
+            a = np.array([rng.randint(0, A) if rng.rand() < p_random else rng.choice(np.flatnonzero(mask[e])) for e in range(E)], np.int64)
+        else:
+            a = choose_actions(policy, rng, obs, mask, size, rotation, p_random, bool(rotation))
         obs, reward, done, infos = venv.step(torch.from_numpy(a).unsqueeze(1))
-        mask = loop_masks(obs, size, False)
+        mask = loop_masks(obs, size, rotation)
         cols["actions"].append(a)
         cols["obs"].append(exact(obs.numpy(), np.uint8))
         cols["mask"].append(exact(mask, np.uint8))
@@ -333,12 +417,19 @@ def dataset_case(name, path, size, E, steps, seed, p_random, out_dir):
     pool = np.empty((E * K,) + ds.shape[1:], np.uint8)
     for k in range(K):
         pool[k * E:(k + 1) * E] = ds[(np.arange(E) + k) % ds.shape[0]]
-    rec.update(pool=pool, size=np.array(size, np.int32), rotation=np.int32(0))
-    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    rec.update(pool=pool, size=np.array(size, np.int32), rotation=np.int32(bool(rotation)))
+    path_out = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path_out, **rec)
+    d = rec["done"].astype(bool)
+    print("%-22s E=%d steps=%d episodes=%d  mean final ratio %.3f  -> %s (%d KB)" % (
+        name, E, steps, int(d.sum()), float(rec["ratio"][d].mean()) if d.any() else 0.0, os.path.basename(path_out),
+        os.path.getsize(path_out) // 1024))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--live":
         live_case(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--deep":
+        deep()
     else:
         main()

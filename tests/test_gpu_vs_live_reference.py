@@ -85,7 +85,8 @@ def test_hip_replays_live_reference_recording(bpp, recordings, case, path):
             check_rollout(lambda pool, size, rot, E, rule: _ScatteredEnv(bpp, pool, size, rot, g["env_ids"], int(g["env_total"]), rule), g)
         else:
             check_rollout(lambda pool, size, rot, E, rule: _Env(bpp, pool, size, rot, E, rule), g)
-        assert g["done"].sum() > (200 if g["actions"].shape[1] >= 64 else 30)
+        assert g["done"].sum() > live_reference.min_episodes(case, g)
+        live_reference.check_depth(case, g)
     finally:
         bpp._lib.set_knobs(**old)
 

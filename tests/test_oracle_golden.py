@@ -4,7 +4,7 @@ float32(float64 arithmetic), ratios/returns are float64 sums in step order)."""
 import numpy as np
 import pytest
 
-from conftest import MASK_CASES, ROLLOUT_CASES, load_golden
+from conftest import DEEP_CASES, MASK_CASES, ROLLOUT_CASES, depth_profile, load_golden
 
 
 def check_rollout(env_factory, g):
@@ -51,6 +51,21 @@ def check_masks(mask_from_obs, mask_from_hmap, g):
 def test_oracle_rollout_matches_reference_golden(oracle, case):
     check_rollout(lambda pool, size, rot, E, rule: oracle.OracleEnv(pool, size, rot, E, mask_rule=rule),
                   load_golden(case))
+
+
+@pytest.mark.parametrize("case", DEEP_CASES)
+def test_deep_fixtures_hold_deep_states(case):
+    """the round-6 fixtures must contain what the uniform-feasible recordings do not -- bins with >= 20
+    boxes on >= 5 % of the recorded env-steps (10x10x10 heuristic cases; 20x20x20: most of them), completely packed bins,
+    and, for the reference's own checkpoints, the utilisation the paper reports for them (~0.7 on CUT-2)."""
+    g = load_golden(case)
+    deep, full, ratio = depth_profile(g)
+    if case.startswith("rollout_deep"):
+        assert deep >= (0.5 if case.endswith("_20") else 0.05), deep
+        assert full >= (0 if case.endswith("_20") else 1), full
+        assert ratio > 0.55
+    else:
+        assert ratio > 0.7 and deep >= 0.04 and g["counter"].max() >= 24
 
 
 @pytest.mark.parametrize("case", MASK_CASES)

@@ -42,7 +42,8 @@ def test_oracle_replays_live_reference_recording(oracle, recordings, case):
         check_rollout(lambda pool, size, rot, E, rule: _ScatteredOracle(oracle, pool, size, rot, g["env_ids"], int(g["env_total"]), rule), g)
     else:
         check_rollout(lambda pool, size, rot, E, rule: oracle.OracleEnv(pool, size, rot, E, mask_rule=rule), g)
-    assert g["done"].sum() > (200 if g["actions"].shape[1] >= 64 else 30)     # a real number of episodes went through the recording
+    assert g["done"].sum() > live_reference.min_episodes(case, g)     # a real number of episodes went through the recording
+    live_reference.check_depth(case, g)                               # ... and the deep cases hold deep states
 
 
 def test_ref_copy_is_byte_identical_to_the_reference_tree():
