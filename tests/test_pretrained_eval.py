@@ -1,0 +1,140 @@
+"""All 2 100 trajectories of the reference's dataset/cut_2.pt under the reference's OWN pretrained checkpoints (VERDICT r5
+#1d).  tests/golden/pretrained_eval_cut2_10{,_rot}.npz hold, per trajectory, what the unmodified reference did --
+PackingGame + LoadBoxCreator driven by acktr.model.Policy.act(deterministic=True) with the true mask, the flow of
+main.py:26-29 -> unified_test.py:29-67 / model_loader.py -- : the actions it took, the terminal info's ratio and counter
+and the float64 sum of its rewards (tests/golden/make_pretrained_eval.py, run once in the build container).
+
+* CPU: the oracle and the emulated product kernels replay all 2 100 trajectories in ONE batch (bin g = trajectory g, a bin
+  that has finished is left alone with BPP_ACTION_NOOP) and must end every one of them at the recorded lock-step with the
+  recorded ratio / counter / return: assert_array_equal on 2 100 float64 ratios.
+* GPU: the same replay on the HIP path (tile and runtime-geometry kernels), and the CONSUMER run --
+  examples/evaluate_checkpoint.py: the checkpoint loaded into plain torch layers ON THE DEVICE, bpp_masked_act's mode, the
+  whole test set in one batch -- whose per-trajectory results are compared with the recording (a float32 argmax computed by
+  another device's GEMMs may flip on a near-tie, so: >= 97 % of the trajectories identical to the last digit, the mean
+  utilisation within 0.003 of the reference's) and written to profiles/ for the README line.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+NOOP = -2 ** 63
+CASES = [("pretrained_eval_cut2_10", False, "default_cut_2.pt"), ("pretrained_eval_cut2_10_rot", True, "rotation_cut_2.pt")]
+
+
+def dataset_pool():
+    """tests/golden/cut2_dataset_10.npz = dataset/cut_2.pt in file order: row r = trajectory r (LoadBoxCreator's appended
+    [10, 10, 10], binCreator.py:62, is the pool's padding)."""
+    return load_golden("cut2_dataset_10")["pool"]
+
+
+def replay(make_env, g):
+    """Bin i plays trajectory i with the recorded actions; returns nothing, asserts everything."""
+    pool = dataset_pool()
+    n, T = g["actions"].shape
+    assert n == pool.shape[0] == 2100
+    env = make_env(pool, tuple(int(v) for v in g["size"]), int(g["rotation"]), n)
+    env.reset()
+    steps = g["steps"]
+    ratio, counter, ret = np.full(n, -1.0), np.full(n, -1, np.int32), np.full(n, -1.0)
+    for t in range(T):
+        live = t < steps
+        a = np.where(live, g["actions"][:, t].astype(np.int64), NOOP)
+        o = env.step(a)
+        done = o["done"].astype(bool)
+        np.testing.assert_array_equal(done, live & (t == steps - 1), err_msg="episode ends at lock-step %d" % t)
+        ratio[done], counter[done], ret[done] = o["ratio"][done], o["counter"][done], o["ep_ret"][done]
+        np.testing.assert_array_equal(o["ep_len"][done], steps[done])
+    np.testing.assert_array_equal(ratio, g["ratio"])
+    np.testing.assert_array_equal(counter, g["counter"])
+    np.testing.assert_array_equal(ret, g["ep_ret"])
+
+
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_fixture_is_the_reference_evaluation(case, rot, ckpt):
+    """Shape of the recording: 2 100 trajectories, every episode ends on the terminator or an infeasible item, utilisation
+    in the range the paper reports for these checkpoints on CUT-2 (0.66 - 0.70 without lookahead)."""
+    g = load_golden(case)
+    assert g["actions"].shape[0] == 2100 and int(g["rotation"]) == int(rot)
+    assert (g["steps"] == g["counter"] + 1).all()          # the failing step is counted in the length, not in the boxes
+    assert 0.65 < g["ratio"].mean() < 0.72 and g["counter"].mean() > 17
+    assert (g["ratio"] == 1.0).sum() >= 3                  # completely packed bins are in there
+
+
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_oracle_replays_all_2100_trajectories(oracle, case, rot, ckpt):
+    replay(lambda pool, size, r, n: oracle.OracleEnv(pool, size, r, n), load_golden(case))
+
+
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_emulated_kernels_replay_all_2100_trajectories(emu, case, rot, ckpt):
+    emu.set_knobs()
+    replay(lambda pool, size, r, n: emu.EmuEnv(pool, size, r, n), load_golden(case))
+
+
+class _GpuEnv(object):
+    def __init__(self, bpp, pool, size, rot, n):
+        self.env = bpp.BppVecEnv(n, size, enable_rotation=bool(rot), pool=pool)
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, a):
+        r = self.env.step_tensors(np.asarray(a))
+        return {k: getattr(r, k).cpu().numpy().reshape(-1) for k in ("done", "ratio", "counter", "ep_ret", "ep_len")}
+
+
+@pytest.fixture(scope="module")
+def bpp():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import bpp_amd
+    bpp_amd._lib.lib()
+    return bpp_amd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["tile", "rt"])
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_hip_replays_all_2100_trajectories(bpp, case, rot, ckpt, path):
+    old = bpp._lib.set_knobs(bins_per_wave=0, waves_per_group=0, xcd_remap=1, force_generic=0, legacy_fast=int(path == "rt"))
+    try:
+        replay(lambda pool, size, r, n: _GpuEnv(bpp, pool, size, r, n), load_golden(case))
+    finally:
+        bpp._lib.set_knobs(**old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_consumer_evaluation_of_the_reference_checkpoint(bpp, case, rot, ckpt):
+    """examples/evaluate_checkpoint.py on the GPU box: checkpoint and dataset from oracle/_ref/ (byte-for-byte copies of the
+    reference's files, oracle/make_ref.py) -- DATA files only; no reference code runs here."""
+    import sys
+    from oracle import ref_shims
+    if not ref_shims.copy_available() or not os.path.isfile(os.path.join(ref_shims.REF_COPY, "pretrained_models", ckpt)):
+        pytest.skip("oracle/_ref/ without the checkpoints (python oracle/make_ref.py)")
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import evaluate_checkpoint as ev
+    g = load_golden(case)
+    r = ev.evaluate(os.path.join(ref_shims.REF_COPY, "pretrained_models", ckpt), os.path.join(ref_shims.REF_COPY, "dataset", "cut_2.pt"),
+                    rotation=rot)
+    same = (r["ratio"] == g["ratio"]) & (r["counter"] == g["counter"])
+    out = {"checkpoint": "pretrained_models/" + ckpt, "dataset": "dataset/cut_2.pt", "trajectories": int(len(same)),
+           "lock_steps": int(r["lock_steps"]), "seconds": round(float(r["seconds"]), 3),
+           "mean_space_utilisation": float(r["ratio"].mean()), "mean_items_packed": float(r["counter"].mean()),
+           "completely_packed_bins": int((r["ratio"] == 1.0).sum()),
+           "reference": {"mean_space_utilisation": float(g["ratio"].mean()), "mean_items_packed": float(g["counter"].mean()),
+                         "completely_packed_bins": int((g["ratio"] == 1.0).sum()),
+                         "source": "tests/golden/%s.npz (the unmodified reference env + Policy, CPU)" % case},
+           "trajectories_identical_to_the_last_digit": int(same.sum()),
+           "note": "replaying the reference's recorded ACTIONS gives 2100 / 2100 identical (test_hip_replays_all_2100_trajectories); "
+                   "this run computes its own actions with the network on the GPU -- a float32 argmax may flip on a near-tie"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r6_eval_%s.json" % case), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+    assert same.mean() >= 0.97, same.mean()
+    assert abs(r["ratio"].mean() - g["ratio"].mean()) < 0.003
