@@ -262,7 +262,29 @@ def self_launch(args):
     env = dict(os.environ, BPP_BENCH_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    tmp = None
+    if not args.no_cpu_baseline:
+        # north_star: the reference timed "on the same box's host cores in the same run" next to EVERY N.  Timed here, once,
+        # before the ranks exist (nothing else runs on the host cores), and handed to rank 0 through a file.
+        import tempfile
+        import bpp_amd
+        size = tuple(args.size)
+        pool = (bpp_amd.sequences.from_dataset(args.pool_file, size, terminator=(10, 10, 10) if size == (10, 10, 10) else size)
+                if args.pool_file else bpp_amd.sequences.cut2_pool(size, args.pool, seed=0))
+        try:
+            cb = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+        except Exception as exc:  # noqa: BLE001
+            cb = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port", "sample": "cpu baseline failed: %r" % (exc,)}
+        cb["timed_by"] = "the self-launching parent process, before the %d ranks were started" % args.gpus
+        fd, tmp = tempfile.mkstemp(prefix="bpp_cpu_baseline_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(cb, f)
+        env["BPP_BENCH_CPU_BASELINE_FILE"] = tmp
+    try:
+        return subprocess.call(cmd, env=env)
+    finally:
+        if tmp and os.path.exists(tmp):
+            os.unlink(tmp)
 
 
 class Ctx(object):
@@ -678,6 +700,37 @@ def workload_text(spec, res, only_sets=False):
                 " [--past-l3-only: EVERY region writes rotating output sets]" if only_sets else ""))
 
 
+def n1_leg(ctx, spec, seconds=0.6):
+    """N > 1 only: the SAME workload on rank 0 ALONE, in the same run on the same box (the other ranks wait at the fence),
+    so that the line carries its own N = 1 figure and the scaling efficiency can be read off it: `n1_value_same_run`.
+    Same timed region as the job's (K lock-steps by one native call between synchronisations), median of the repetitions
+    that fit `seconds`; no collective inside (there is nobody to talk to)."""
+    args, torch = ctx.args, ctx.torch
+    ctx.fence()
+    out = None
+    if ctx.rank == 0:
+        E = spec["envs"]
+        env = ctx.bpp.BppVecEnv(E, spec["size"], enable_rotation=spec["rotation"], pool=spec["pool"], device=ctx.device,
+                                env_id_base=0, env_id_total=E)
+        actions = torch.empty(E, dtype=torch.int64, device=ctx.device)
+        env.reset()
+        env.rollout_uniform_sets(1, 0, args.warmup, actions, resume=False)
+        t, samples, spent = args.warmup, [], 0.0
+        while len(samples) < 3 or (spent < seconds and len(samples) < 20000):
+            torch.cuda.synchronize(ctx.device)
+            t0 = time.perf_counter()
+            env.rollout_uniform_sets(1, t, args.steps, actions, resume=True)
+            torch.cuda.synchronize(ctx.device)
+            samples.append(time.perf_counter() - t0)
+            spent += samples[-1]
+            t += args.steps
+        dt = sorted(samples)[len(samples) // 2]
+        out = {"value": E * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "reps": len(samples),
+               "what": "rank 0 alone on its GPU, %d bins, the other %d rank(s) idle at a barrier; one output set" % (E, ctx.world - 1)}
+    ctx.fence()
+    return out
+
+
 def main():
     args = parse()
     spawned = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -724,16 +777,26 @@ def main():
                                                "LoadBoxCreator's order): SURVEY 8d's PRIMARY pool of config 2",
                                 "gpu_seconds": 0.6 * xs, "l3_seconds": 0.5 * xl, "parity": not args.no_parity, "parity_steps": 24})
     cpu_base = None
-    if world == 1 and not args.no_cpu_baseline:
-        # before the HIP runtime is initialised in this process: the baseline forks one worker per core
-        try:
-            cpu_base = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
-        except Exception as exc:  # noqa: BLE001 -- the baseline leg must never take the GPU measurement down
-            cpu_base = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port",
-                        "sample": "cpu baseline failed: %r" % (exc,)}
+    handed = os.environ.get("BPP_BENCH_CPU_BASELINE_FILE")
+    if rank == 0 and not args.no_cpu_baseline:
+        if handed and os.path.exists(handed):          # timed by the self-launching parent before the ranks started
+            cpu_base = json.load(open(handed))
+        else:
+            # before the HIP runtime is initialised in this process: the baseline forks one worker per core.  With N > 1
+            # ranks started by a launcher this is rank 0's job as well (the other ranks wait in the rendezvous of
+            # init_process_group below, blocked, not spinning): the N = 2 / 4 / 8 lines carry the reference timed on
+            # the same box in the same run, as north_star asks.
+            try:
+                cpu_base = cpu_baseline(pool, size, args.rotation, args.cpu_seconds)
+            except Exception as exc:  # noqa: BLE001 -- the baseline leg must never take the GPU measurement down
+                cpu_base = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port",
+                            "sample": "cpu baseline failed: %r" % (exc,)}
+            if world > 1:
+                cpu_base["timed_by"] = "rank 0 before any rank touched its GPU (the other %d ranks waited in the rendezvous)" % (world - 1)
     ctx.init_device()
     res = run_workload(ctx, main_spec)
     extras = [run_workload(ctx, sp) for sp in extra_specs]
+    n1 = n1_leg(ctx, main_spec) if world > 1 and not args.stream else None
 
     if rank == 0:
         samples, dt, past, summary = res["samples"], res["dt"], res["past"], res["summary"]
@@ -809,6 +872,11 @@ def main():
                     "roofline": roofline_block(ctx, r), "parity": r["parity"]}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        if n1 is not None:
+            out["n1_value_same_run"] = n1["value"]
+            out["n1_same_run"] = n1
+            out["scaling_efficiency_same_run"] = out["value"] / (world * n1["value"])
+            out["roofline"]["per_gpu"] = True      # rank 0's kernel on rank 0's GPU; every rank runs the same launch on its own shard
         print(json.dumps(out), flush=True)
     if ctx.use_pg:
         ctx.dist.destroy_process_group()

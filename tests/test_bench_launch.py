@@ -37,7 +37,14 @@ def test_self_launch_command_line(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 7
 
+    def fake_call(cmd, env=None):      # noqa: F811 -- also looks at what the parent hands to rank 0
+        seen["cmd"], seen["env"] = cmd, env
+        seen["handed"] = json.load(open(env["BPP_BENCH_CPU_BASELINE_FILE"]))
+        return 7
+
     monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(bench, "cpu_baseline", lambda pool, size, rot, seconds: {"value": 1.0, "unit": "env steps/s", "cores": 1,
+                                                                                 "kind": "port", "sample": "stub"})
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "20", "--warmup", "5"])
     for k in ("WORLD_SIZE", "RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -49,6 +56,9 @@ def test_self_launch_command_line(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "3" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "3", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["BPP_BENCH_CHILD"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the reference is timed ONCE, by the parent, before the ranks exist, and handed to rank 0
+    assert seen["handed"]["sample"] == "stub" and "before the 3 ranks" in seen["handed"]["timed_by"]
+    assert not os.path.exists(seen["env"]["BPP_BENCH_CPU_BASELINE_FILE"])          # ... and the hand-over file is gone afterwards
 
 
 @pytest.mark.gpu
@@ -58,7 +68,8 @@ def test_gpu_bench_two_ranks_without_a_launcher():
     d = _run(["--gpus", "2", "--steps", "20", "--warmup", "5", "--only-headline"], BPP_BENCH_ONE_DEVICE="1")
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and d["steps"] == 20 and d["warmup"] == 5
     assert d["config"]["launcher"] == "self-launched torch.distributed.run"
-    assert d["value"] > 1e8 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["value"] > 1e8 and d["scaling"] == "weak"
+    _check_multi_rank_line(d, 2)
     assert d["timed_gpu_work_ms"] >= 150.0
     assert d["config"]["episodes_finished"] > 0
     assert d["parity"]["mismatches"] == 0 and d["parity"]["checked_bins"] == 512      # every rank gates its own shard
@@ -84,7 +95,43 @@ def test_gpu_bench_eight_ranks_on_one_device_shard_by_global_id():
     np.testing.assert_allclose(parts[:, :2].sum(axis=0), whole[:2], rtol=1e-13, atol=0)
     assert d["config"]["episodes_finished"] == int(whole[3])
     assert d["parity"]["mismatches"] == 0 and d["parity"]["checked_bins"] == 8 * 256 and d["parity"]["per_workload"]["10x10x10"]["ranks"] == 8
-    assert d["value"] > 1e7 and "cpu_baseline" not in d      # (eight processes taking turns on one device: ~6e7 measured)
+    assert d["value"] > 1e7      # (eight processes taking turns on one device: ~6e7 measured)
+    _check_multi_rank_line(d, 8)
+    assert "self-launching parent" in d["cpu_baseline"]["timed_by"]
+
+
+def _check_multi_rank_line(d, n):
+    """an N > 1 line is complete by itself -- the reference timed on the same box in the same run
+    (`cpu_baseline`, kind "reference" where oracle/_ref/ travelled), the roofline block of one GPU, and the same
+    workload on rank 0 ALONE in the same run (`n1_value_same_run`), from which the scaling efficiency follows."""
+    c = d["cpu_baseline"]
+    assert c["value"] and c["value"] > 1e3 and c["cores"] >= 1 and c["kind"] in ("reference", "port") and c["sample"]
+    assert "timed_by" in c
+    r = d["roofline"]
+    assert r["per_gpu"] is True and r["bound"] == "hbm" and 0.0 < r["frac"] < 1.05 and r["bytes_per_env_step"] == 2864
+    assert d["n1_value_same_run"] > 1e7 and d["n1_same_run"]["reps"] >= 3
+    assert abs(d["scaling_efficiency_same_run"] - d["value"] / (n * d["n1_value_same_run"])) < 1e-9
+    # ranks SHARING one device take turns on it: the job cannot be faster than the device alone (and is not 10x slower)
+    assert 0.1 < d["value"] / d["n1_value_same_run"] < 1.3
+
+
+@pytest.mark.gpu
+def test_gpu_bench_launcher_started_ranks_time_the_reference_on_rank0():
+    """What the driver does for N > 1: `python -m torch.distributed.run ... bench.py --gpus 2` -- no self-launching parent,
+    so rank 0 itself times the reference before any rank touches its GPU, and the line says so."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--only-headline", "--gpu-seconds", "0.5", "--cpu-seconds", "8"]
+    p = subprocess.run(cmd, env=_clean_env(BPP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["launcher"] == "torch.distributed.run"
+    _check_multi_rank_line(d, 2)
+    assert "rank 0" in d["cpu_baseline"]["timed_by"]
 
 
 @pytest.mark.gpu
