@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BPP_ABI_VERSION 15
+#define BPP_ABI_VERSION 16
 
 #define BPP_E_BADARG   (-1)  /* NULL pointer, non-positive size, unknown rule ... */
 #define BPP_E_TOOLARGE (-2)  /* W*L or H beyond what the kernels support (see bpp_limits) */
@@ -369,6 +369,11 @@ int bpp_wait(void *stream);
  * store instead of after a signal round trip.  Use a value the word does not hold yet. */
 int bpp_mark(void *host_flag, uint32_t value, void *stream);
 int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream);
+/* Visibility: the word and the data it announces (reward / done / the eager gather's arrays) are plain stores into page-locked
+ * host memory; the host may read the data as soon as it sees the word only if that memory is host-COHERENT (hipHostMalloc's
+ * default; torch's pin_memory()).  bpp_mark asks the runtime for the flag's allocation flags once per buffer address range; for
+ * memory allocated hipHostMallocNonCoherent it enqueues the marker KERNEL instead of the stream memory operation (its store is a
+ * system-scope release behind a system-scope fence), and bpp_wait_mark ends with a stream synchronisation for such a flag. */
 
 /* `infos` of the bins that finished in a lock-step (main.py:159-162 reads infos[i]['episode']['r'] and infos[i]['ratio']
  * of exactly those; bench/monitor.py:64-75, bin3D.py:111).  `n` = the number of finished bins the caller counted in ITS
@@ -392,6 +397,15 @@ int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream);
 int bpp_gather_finished(const uint8_t *done, const double *ep_ret, const double *ratio, const int32_t *ep_len,
                         const int32_t *counter, int32_t E, void *dev, void *host, int32_t n, void *stream);
 
+/* VecEnv.step_async() of the reference-shaped path in ONE host call (v16; replaces baselines/common/vec_env/shmem_vec_env.py:69-79's
+ * one pipe message per worker, acktr/envs.py:182-188): bpp_step(b, actions, out); then, fin_host != NULL, the eager
+ * bpp_gather_finished of THAT step's outputs (out->done / ep_ret / ratio / ep_len / counter, BPP_GATHER_ENQUEUE_ONLY) into
+ * fin_host; then, host_flag != NULL, bpp_mark(host_flag, value).  Same results as the three calls one after the other; what it
+ * saves is two trips through the caller's FFI per lock-step, which is what a step costs at the reference's own scale (16 ... 1024
+ * bins: the kernels take a few microseconds).  Nothing is waited for. */
+int bpp_step_dropin(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *fin_host, void *host_flag,
+                    uint32_t value, void *stream);
+
 /* Policy-free lock-step driver for benchmarks and soak tests (no reference counterpart): enqueues
  * `nsteps` iterations of { bpp_sample_feasible(out->mask -> actions, step0 + t); bpp_step(actions -> out) }
  * on `stream` from one host call.  out->mask must hold the mask of the current observations (as left
@@ -408,8 +422,10 @@ int bpp_rollout_uniform(const bpp_batch *b, const bpp_step_out *out, int64_t *ac
  * action is drawn from `first_mask`, the mask of the current observations (as left by bpp_reset / bpp_step). */
 #define BPP_ROLLOUT_CONTINUE 1
 /* flags bits 8..31: epsilon of SURVEY.md 8d's failure-path variant as a 24-bit fraction (BPP_ROLLOUT_EPS(0.01 * 2^24) = 1 %):
- * every draw is followed by bpp_epsilon_override with the draw's own (seed, step).  0 = the plain uniform-feasible policy. */
-#define BPP_ROLLOUT_EPS(q24)      ((int32_t)((uint32_t)(q24) << 8))
+ * every draw is followed by bpp_epsilon_override with the draw's own (seed, step).  0 = the plain uniform-feasible policy.  The
+ * field holds 24 bits: the largest epsilon it carries is (2^24 - 1) / 2^24 -- the macro clamps, so epsilon = 1.0 means "all but one
+ * draw in 16.7 million" here, never a wrap-around to 0 (bpp_epsilon_override itself takes the full range 0 .. 2^24). */
+#define BPP_ROLLOUT_EPS(q24)      ((int32_t)(((uint32_t)(q24) > 0xffffffu ? 0xffffffu : (uint32_t)(q24)) << 8))
 #define BPP_ROLLOUT_EPS_OF(flags) ((uint32_t)(flags) >> 8)
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
                              int64_t *actions, uint64_t seed, uint64_t step0, int32_t nsteps, int32_t flags, void *stream);

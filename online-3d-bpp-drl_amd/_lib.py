@@ -17,7 +17,7 @@ LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
 DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_tile_body.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 STREAM_RNG_MT19937, STREAM_RNG_COUNTER = 0, 1
 RULE_UTILS, RULE_SPACE = 0, 1
 RESET_INIT, RESET_ADVANCE = 0, 1
@@ -27,7 +27,7 @@ REDUCE_SCRATCH_BYTES = REDUCE_LANES * 4 * 8 + 64
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override", "bpp_side_create", "bpp_side_destroy", "bpp_mark", "bpp_wait_mark"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override", "bpp_side_create", "bpp_side_destroy", "bpp_mark", "bpp_wait_mark", "bpp_step_dropin"]
 
 
 class Batch(ctypes.Structure):
@@ -64,7 +64,7 @@ def eps_q24(eps):
 
 def rollout_eps_flags(eps):
     """BPP_ROLLOUT_EPS(q24): the flags bits of bpp_rollout_uniform_sets that carry epsilon, as the int32 the ABI takes"""
-    v = (eps_q24(eps) << 8) & 0xFFFFFFFF
+    v = (min(eps_q24(eps), (1 << 24) - 1) << 8) & 0xFFFFFFFF      # the field holds 24 bits: eps = 1.0 is clamped, not wrapped to 0
     return v - (1 << 32) if v & 0x80000000 else v
 
 
@@ -160,6 +160,8 @@ def lib():
         L.bpp_wait.argtypes = [ctypes.c_void_p]
         L.bpp_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_wait_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.bpp_step_dropin.argtypes = [ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_gather_finished.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_fetch_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.bpp_episode_acc_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]

@@ -2749,12 +2749,46 @@ int bpp_wait(void *stream) {
     return e == hipSuccess ? 0 : hip_fail(e, "hipStreamSynchronize");
 }
 
+// Is the page-locked allocation `p` lies in host-coherent?  (the spin-wait reads data the device wrote as soon as the
+// word arrives -- correct only for coherent host memory.)  Asked once per 2 MiB-aligned address range and remembered; memory the
+// runtime does not know as page-locked counts as non-coherent (the marker kernel + a final synchronisation are always right).
+bool host_flag_coherent(const void *p) {
+    static std::mutex m;
+    static std::vector<std::pair<uintptr_t, bool>> seen;
+    const uintptr_t key = (uintptr_t)p >> 21;
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (const auto &kv : seen)
+            if (kv.first == key) return kv.second;
+    }
+    unsigned int flags = 0;
+    bool coherent = false;
+    if (hipHostGetFlags(&flags, const_cast<void *>(p)) == hipSuccess) coherent = (flags & hipHostMallocNonCoherent) == 0;
+    else (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(m);
+    if (seen.size() > 256) seen.clear();
+    seen.emplace_back(key, coherent);
+    return coherent;
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
 int bpp_mark(void *host_flag, uint32_t value, void *stream) {
     if (!host_flag || ((uintptr_t)host_flag & 3u)) return fail(BPP_E_BADARG, "bpp_mark: NULL / misaligned flag");
-    static std::atomic<int> use_kernel{0};      // the stream memory operation failed once in this process: marker kernel from then on
-    if (!use_kernel.load(std::memory_order_relaxed)) {
-        if (hipStreamWriteValue32((hipStream_t)stream, host_flag, value, 0) == hipSuccess) return 0;
+    // the stream memory operation is not offered by this runtime / device (hipErrorNotSupported once): marker kernel from then
+    // on.  Any OTHER error of the call is the caller's (a bad stream ...) and is reported, not hidden behind the fallback.
+    static std::atomic<int> use_kernel{0};
+    if (!use_kernel.load(std::memory_order_relaxed) && host_flag_coherent(host_flag)) {
+        const hipError_t w = hipStreamWriteValue32((hipStream_t)stream, host_flag, value, 0);
+        if (w == hipSuccess) return 0;
         (void)hipGetLastError();
+        if (w != hipErrorNotSupported) return hip_fail(w, "hipStreamWriteValue32");
         use_kernel.store(1, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t *)host_flag, value);
@@ -2765,8 +2799,15 @@ int bpp_mark(void *host_flag, uint32_t value, void *stream) {
 int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream) {
     if (!host_flag) return fail(BPP_E_BADARG, "bpp_wait_mark: NULL flag");
     const uint32_t *f = (const uint32_t *)host_flag;
+    const bool coherent = host_flag_coherent(host_flag);
     for (uint32_t spins = 1;; ++spins) {
-        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == value) return 0;
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == value) {
+            if (!coherent) {        // the data the word announces may still sit in the device's caches: let the runtime finish the job
+                const hipError_t q = hipStreamSynchronize((hipStream_t)stream);
+                if (q != hipSuccess) return hip_fail(q, "hipStreamSynchronize");
+            }
+            return 0;
+        }
         if ((spins & 0xfffu) == 0) {            // every few microseconds: is the stream still alive?
             hipError_t q = hipStreamQuery((hipStream_t)stream);
             if (q == hipSuccess) {              // all done and the word not seen yet: synchronise, look once more
@@ -2777,8 +2818,18 @@ int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream) {
             }
             if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery");
         }
-        __builtin_ia32_pause();
+        cpu_relax();
     }
+}
+
+int bpp_step_dropin(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *fin_host, void *host_flag,
+                    uint32_t value, void *stream) {
+    int rc = bpp_step(b, actions, out, stream);
+    if (rc == 0 && fin_host)
+        rc = bpp_gather_finished(out->done, out->ep_ret, out->ratio, out->ep_len, out->counter, b->num_envs, nullptr, fin_host,
+                                 BPP_GATHER_ENQUEUE_ONLY, stream);
+    if (rc == 0 && host_flag) rc = bpp_mark(host_flag, value, stream);
+    return rc;
 }
 
 int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32_t nsets, const float *first_mask,
@@ -2790,7 +2841,6 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
     if (nsteps == 0) return 0;
     const int M = b->W * b->L * (1 + b->rotation);
     const uint32_t eps = BPP_ROLLOUT_EPS_OF(flags);     // SURVEY 8d's failure-path variant: one tiny launch behind every draw
-    if (eps > (1u << 24)) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: epsilon > 1");
     int rc = 0;
     if (!(flags & BPP_ROLLOUT_CONTINUE)) {
         if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");

@@ -70,7 +70,7 @@ constexpr int round16(int v) { return (v + 15) & ~15; }
 // constant memory, one 32-byte entry per footprint, built at compile time for the two tile geometries (round 4 computed
 // them per launch and bin: ~60 of a wave's ~680 vector instructions, executed by 4 of its 64 lanes); what is left per slot
 // is the table index, the height bound hz1 and three flag bits.
-struct SlotEntry {
+struct alignas(32) SlotEntry {   // one entry = one 32-byte line; make_slot_words reads it as a 16-byte and an 8-byte load
     uint32_t w[8];   // w0 .. w5 as documented above with hz1 = 0 and fresh = 0; bit 31 of w1 = "x == y" (square candidate); w6, w7 unused
 };
 template <int W, int L>

@@ -128,7 +128,7 @@ class LazyInfos(object):
         self._env = env
         self._res = res
         self._t = t_now
-        self._done = None if done is None else np.asarray(done).astype(bool)
+        self._done = None if done is None else (done if isinstance(done, np.ndarray) and done.dtype == np.bool_ else np.asarray(done).astype(bool))
         self._serial = serial
         self._fin = fin        # (bins, [ep_ret, ratio], [ep_len, counter]) of the finished bins; handed in by an env with eager_infos
         self._live = None      # (counter, ratio) arrays of all bins
@@ -216,8 +216,9 @@ class LazyInfos(object):
         return (self[i] for i in range(len(self)))
 
     def done_indices(self):
+        """Local numbers of the bins that finished in this step, ascending, as a fresh intp array (whatever was accessed before)."""
         if self._fin is not None:          # (eager_infos: the compaction's bin list is the answer, ascending)
-            return self._fin[0]
+            return self._fin[0].astype(np.intp)
         return np.flatnonzero(self._done_mask())
 
 
@@ -633,12 +634,13 @@ class BppVecEnv(object):
         self._tstart = time.time()
         return bufs["obs"]
 
-    def step_tensors(self, actions, sample=None, _host=None):
+    def step_tensors(self, actions, sample=None, _host=None, _dropin=None):
         """Enqueue one lock-step; returns device tensors, never synchronises.  actions: int64 [E] or [E,1].
         sample=(seed, step, out): additionally draw, inside the step kernel, the uniform-feasible action
         for the NEW observation into int64 tensor `out` [E] (== sample_feasible(seed, step) on the new mask;
         `out` may be the action tensor itself).  (_host: page-locked numpy byte buffer the kernel mirrors reward and
-        done into -- step_async's business.)"""
+        done into; _dropin = (fin_host pointer or None, completion-word pointer or None, value): bpp_step_dropin instead of
+        bpp_step -- step_async's business.)"""
         if self._first_reset:
             raise RuntimeError("call reset() before step()")
         a = actions
@@ -667,7 +669,10 @@ class BppVecEnv(object):
         else:
             out.host_reward = out.host_done = None
         self._last_stream = sp = self._stream_ptr()
-        rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
+        if _dropin is None:
+            rc = self.lib.bpp_step(self._batch_ref, a.data_ptr(), ctypes.byref(out), sp)
+        else:       # step + eager gather of the finished bins + completion word: ONE trip through ctypes (ABI v16)
+            rc = self.lib.bpp_step_dropin(self._batch_ref, a.data_ptr(), ctypes.byref(out), _dropin[0], _dropin[1], _dropin[2], sp)
         if rc:
             _lib.check(rc)
         self._serial += 1
@@ -736,26 +741,33 @@ class BppVecEnv(object):
             self._res = self._bufs
         return self._res
 
+    def _stage_offsets(self):
+        """(reward offset, done offset, eager gather's offset or None, completion word's offset) inside a staging buffer."""
+        key = (self.E, bool(self.eager_infos))
+        so = getattr(self, "_stage_offs", None)
+        if so is None or so[0] != key:
+            offs = self._layout()[2]
+            so = self._stage_offs = (key, offs["reward"], offs["done"], self._fin_offset() if self.eager_infos else None, self._mark_offset())
+        return so
+
     def step_async(self, actions, sample=None):
         """The reference-shaped path: the step kernel also writes reward and done (5 bytes per bin) straight into a
-        page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing.
+        page-locked host buffer (bpp_step_out.host_reward / host_done), so step_wait() copies nothing.  ONE native call
+        (bpp_step_dropin) enqueues the step, with eager_infos the compaction of the finished bins' (r, ratio, l, counter, bin)
+        into the same buffer, and the step's completion word behind both.
         sample=(seed, step, out): as in step_tensors -- also draw a uniform-feasible action for the new observation."""
         host = self._staging(mapped=True)      # None: every page-locked buffer is still referenced -> step_wait() copies
-        res = self.step_tensors(actions, sample=sample, _host=host)
-        if self.eager_infos and host is not None:
-            # the finished bins' (r, ratio, l, counter, bin), compacted in bin order straight into this step's page-locked buffer by
-            # one more launch behind the step kernel: step_wait()'s ONE synchronisation covers it (bpp_gather_finished, eager form)
-            base, lay = res._flat.data_ptr(), res._layout
-            rc = self.lib.bpp_gather_finished(base + lay["done"][0], base + lay["ep_ret"][0], base + lay["ratio"][0], base + lay["ep_len"][0],
-                                              base + lay["counter"][0], self.E, None, host.ctypes.data + self._fin_offset(), -1, self._last_stream)
-            if rc:
-                _lib.check(rc)
+        if host is None:
+            res = self.step_tensors(actions, sample=sample)
+            self._pending = (res, None, self._last_stream, None)
+            return
+        _, _, _, fin_off, mark_off = self._stage_offsets()
+        base = host.ctypes.data
         mark = None
-        if host is not None and self.spin_wait:   # the step's serial number lands in the buffer when everything above is complete: step_wait() spins on it
+        if self.spin_wait:   # the step's serial number lands in the buffer when everything is complete: step_wait() spins on it
             mark = self._mark = (self._mark + 1) & 0xffffffff or 1       # (never a value the buffer's word still holds from an earlier step)
-            rc = self.lib.bpp_mark(host.ctypes.data + self._mark_offset(), self._mark, self._last_stream)
-            if rc:
-                _lib.check(rc)
+        res = self.step_tensors(actions, sample=sample, _host=host,
+                                _dropin=(base + fin_off if fin_off is not None else None, base + mark_off if mark is not None else None, mark or 0))
         self._pending = (res, host, self._last_stream, mark)      # the stream THIS step went to (observe() etc. may overwrite _last_stream)
 
     def step_wait(self):
@@ -764,24 +776,25 @@ class BppVecEnv(object):
             raise RuntimeError("step_wait() without step_async()")
         (r, host, stream, mark), self._pending = self._pending, None
         fin = None
+        E = self.E
         if host is None:
             rew, done = r.host_reward_done(stream)          # one 5-byte-per-bin copy + stream synchronise
             done = done.view(np.bool_)
+            reward = torch.from_numpy(rew).unsqueeze(1)
         else:
+            _, ro, do, fin_off, mark_off = self._stage_offsets()
             # the kernel wrote reward / done into `host` itself: wait for the step's completion word (or synchronise the stream)
-            rc = self.lib.bpp_wait_mark(host.ctypes.data + self._mark_offset(), mark, stream) if mark is not None else self.lib.bpp_wait(stream)
+            rc = self.lib.bpp_wait_mark(host.ctypes.data + mark_off, mark, stream) if mark is not None else self.lib.bpp_wait(stream)
             if rc:
                 _lib.check(rc)
-            offs, E = self._layout()[2], self.E
-            rew = host[offs["reward"]:offs["reward"] + 4 * E].view("<f4")
-            done = host[offs["done"]:offs["done"] + E].view(np.bool_)       # the kernels write exactly 0 / 1
-            if self.eager_infos:        # the gather enqueued by step_async is complete too: slice the five arrays (copies: ~28 B per finished bin)
-                fo, E8 = self._fin_offset() + 32, 8 * E
+            reward = torch.from_numpy(host[ro:ro + 4 * E].view("<f4").reshape(E, 1))       # CPU [E,1], acktr/envs.py:192
+            done = host[do:do + E].view(np.bool_)       # the kernels write exactly 0 / 1
+            if fin_off is not None:     # the gather enqueued with the step is complete too: slice the five arrays (copies: ~28 B per finished bin)
+                fo, E8 = fin_off + 32, 8 * E
                 n = int(host[fo - 32:fo - 28].view("<i4")[0])
                 fin = (host[fo + 3 * E8:fo + 3 * E8 + 4 * n].view("<i4").copy(),
                        (host[fo:fo + 8 * n].view("<f8").copy(), host[fo + E8:fo + E8 + 8 * n].view("<f8").copy()),
                        (host[fo + 2 * E8:fo + 2 * E8 + 4 * n].view("<i4").copy(), host[fo + 2 * E8 + 4 * E:fo + 2 * E8 + 4 * E + 4 * n].view("<i4").copy()))
-        reward = torch.from_numpy(rew).unsqueeze(1)                                     # CPU [E,1], acktr/envs.py:192
         t_now = time.time()
         infos = LazyInfos(self, r, t_now, done=done, serial=self._serial, fin=fin)
         if self.monitor is not None and done.any():         # bench/monitor.py:58-72: a row per finished episode
@@ -964,9 +977,16 @@ class BppVecEnv(object):
         if self._stream is not None:
             if "stream_ring" not in sd:
                 raise ValueError("checkpoint of a pool-based env loaded into a streaming env")
-            if int(sd.get("stream_layout", 1)) != STREAM_LAYOUT:
+            layout = sd.get("stream_layout")
+            if layout is None:
+                # checkpoints written before the key existed: layout 1 (ABI <= 11) kept raw 32-bit MT19937 outputs -- another
+                # record width than layout 2's byte outputs (ABI 12 / 13 wrote layout 2 without saying so) -- and rows without the
+                # two look-ahead entries: the buffer shapes tell them apart
+                same = (tuple(sd["stream_ring"].shape) == tuple(self.pool.shape) and tuple(sd["stream_mt"].shape) == tuple(self._mt.shape))
+                layout = STREAM_LAYOUT if same else 1
+            if int(layout) != STREAM_LAYOUT:
                 raise ValueError("streaming checkpoint with ring / generator layout %d, this build reads layout %d: its rows would be "
-                                 "played as other items" % (int(sd.get("stream_layout", 1)), STREAM_LAYOUT))
+                                 "played as other items" % (int(layout), STREAM_LAYOUT))
             want, got = self._stream_identity(), sd.get("stream_spec")
             if got is not None:
                 got = dict(got)

@@ -522,6 +522,16 @@ int bpp_wait_mark(const void *host_flag, uint32_t value, void *stream) {
     return *(const uint32_t *)host_flag == value ? 0 : fail(BPP_E_BADARG, "bpp_wait_mark: the flag does not hold the value (no bpp_mark?)");
 }
 
+int bpp_step_dropin(const bpp_batch *b, const int64_t *actions, const bpp_step_out *out, void *fin_host, void *host_flag,
+                    uint32_t value, void *stream) {      /* include/bpp_abi.h: the three calls one after the other */
+    int rc = bpp_step(b, actions, out, stream);
+    if (rc == 0 && fin_host)
+        rc = bpp_gather_finished(out->done, out->ep_ret, out->ratio, out->ep_len, out->counter, b->num_envs, NULL, fin_host,
+                                 BPP_GATHER_ENQUEUE_ONLY, stream);
+    if (rc == 0 && host_flag) rc = bpp_mark(host_flag, value, stream);
+    return rc;
+}
+
 int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_base, uint64_t seed, uint64_t step, uint32_t eps_q24,
                          void *stream) {
     (void)stream;
@@ -541,7 +551,6 @@ int bpp_rollout_uniform_sets(const bpp_batch *b, const bpp_step_out *outs, int32
     if (nsteps < 0) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: negative nsteps");
     int M = b->W * b->L * (1 + b->rotation), rc = 0;
     uint32_t eps = BPP_ROLLOUT_EPS_OF(flags);
-    if (eps > (1u << 24)) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: epsilon > 1");
     if (nsteps == 0) return 0;
     if (!(flags & BPP_ROLLOUT_CONTINUE)) {
         if (!first_mask) return fail(BPP_E_BADARG, "bpp_rollout_uniform_sets: first_mask needed without BPP_ROLLOUT_CONTINUE");

@@ -276,7 +276,7 @@ def rollout_uniform_sets(env, seed, step0, nsteps, nsets, resume=False, actions=
     a = np.zeros(E, np.int64) if actions is None else actions
     fm = env.out["mask"] if first_mask is None else first_mask
     _check(lib().bpp_rollout_uniform_sets(ctypes.byref(env._b), outs, nsets, _p(fm), _p(a), int(seed), int(step0), int(nsteps),
-                                          ctypes.c_int32(((1 if resume else 0) | (int(round(eps * (1 << 24))) << 8)) & 0xFFFFFFFF).value, None))
+                                          ctypes.c_int32(((1 if resume else 0) | (min(int(round(eps * (1 << 24))), (1 << 24) - 1) << 8)) & 0xFFFFFFFF).value, None))
     return sets, a
 
 

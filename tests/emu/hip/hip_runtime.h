@@ -45,7 +45,8 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 typedef void *hipStream_t;
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorNotReady = 600 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorNotSupported = 801 };
+#define hipHostMallocNonCoherent 0x80000000u
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
@@ -83,6 +84,10 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWriteValue32(hipStream_t, void *p, uint32_t v, unsigned) {   // kernels run at launch here: everything before is complete
     *(uint32_t *)p = v;
+    return hipSuccess;
+}
+static inline hipError_t hipHostGetFlags(unsigned int *flags, void *) {   // plain host memory here: coherent by construction
+    *flags = 0;
     return hipSuccess;
 }
 static inline hipError_t hipGetDevice(int *d) {

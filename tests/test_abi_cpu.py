@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_limits(lib):
-    assert lib.bpp_abi_version() == 15
+    assert lib.bpp_abi_version() == 16
     assert _lib.limits() == (1024, 255)
 
 

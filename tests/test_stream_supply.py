@@ -451,12 +451,16 @@ def test_gpu_stream_checkpoints_are_validated_on_load():
     with pytest.raises(ValueError, match="stream_spec"):
         bpp_amd.BppVecEnv(64, size, stream=spec, env_id_base=64, env_id_total=128).load_state_dict(sd)
     bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(sd)      # the matching env loads
-    # the ring / generator LAYOUT is versioned too -- a checkpoint of another layout (or of a build that did not
-    # record one) is refused even when every buffer happens to have the same shape
+    # the ring / generator LAYOUT is versioned too -- a checkpoint that SAYS it has another layout is refused even
+    # when every buffer happens to have the same shape.  ADVICE r5: a checkpoint without the key (ABI 12 / 13 wrote layout 2
+    # without recording it; layout 1's generator records and rows have other widths) is told apart by its buffer shapes
     assert sd["stream_layout"] == bpp_amd.vec_env.STREAM_LAYOUT
-    for old in (dict(sd, stream_layout=1), {k: v for k, v in sd.items() if k != "stream_layout"}):
-        with pytest.raises(ValueError, match="layout"):
-            bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(old)
+    with pytest.raises(ValueError, match="layout"):
+        bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(dict(sd, stream_layout=1))
+    keyless = {k: v for k, v in sd.items() if k != "stream_layout"}
+    bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(keyless)                 # same shapes: this build's layout
+    with pytest.raises(ValueError, match="layout"):                                   # layout 1's wider generator records
+        bpp_amd.BppVecEnv(64, size, stream=spec).load_state_dict(dict(keyless, stream_mt=sd["stream_mt"][:, :-8].clone()))
     # ... and the automatic row cache is only switched on where the tile step kernel (10x10 / 20x20 bins) keeps it
     assert bpp_amd.BppVecEnv(64, size, stream=dict(spec, depth=8, refill_every=3)).stream_spec["cache"] is True
     odd = bpp_amd.BppVecEnv(64, (7, 13, 8), stream=dict(bound=(2, 4), seed=5, depth=8))
