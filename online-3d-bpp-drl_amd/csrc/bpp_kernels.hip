@@ -1439,143 +1439,157 @@ __global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t 
 }
 
 // Masked categorical action selection (include/bpp_abi.h: bpp_masked_act; acktr/distributions.py:71-84,
-// acktr/model.py:56-68).  16 lanes per bin, PER float4 quads of logits and mask per lane; row maximum,
-// softmax denominator, probability total and the CDF position are reduced/scanned inside the 16-lane row
-// with shuffles.  float32 throughout; exp through the hardware exp2 (__expf, ~2 ulp) and one reciprocal of the softmax
-// denominator per row -- both far inside the 5e-6 log-probability tolerance the torch reference is held to.
+// acktr/model.py:56-68).  16 lanes per bin = one DPP row, PER float4 quads of logits and mask per lane (lane sl owns quads
+// sl, sl + 16, ...: every load instruction of a row is one contiguous 256-byte segment).  Round 6: the kernel is VALU-issue
+// bound, not memory bound -- 65 536 rows of M = 100 are 16 waves per SIMD, and round 1's 680 instructions per wave
+// (38 ds_bpermute shuffles with their address arithmetic, two IEEE divisions, logf, per-element range predicates) were 16.2 us
+// for 53 MB.  Now: row maximum, softmax denominator, probability total, the inclusive scan of the CDF and the index
+// reductions run on the DPP data path (row_ror / row_shr: one VALU instruction each, no LDS), the reciprocals and the
+// logarithm are the hardware's (v_rcp_f32 / v_log_f32, 1 ulp: far inside the 5e-6 log-probability tolerance the torch
+// reference is held to), a quad past the end of the row is a -inf logit instead of a predicate per element, the sampled
+// entry is found by COUNTING the cumulative sums below the target, and the lane that owns the chosen entry writes the outputs
+// (no broadcast of its probability): ~340 instructions per wave.
+// row_ror:n rotates within every 16-lane row; row_shr:n shifts, lanes without a source keep `old`
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v, float old) {
+    (void)old;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v, int old) {
+    (void)old;
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
 __device__ __forceinline__ float row16_max(float v) {
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 16));
+    v = fmaxf(v, dpp_f<0x128>(v, v)); v = fmaxf(v, dpp_f<0x124>(v, v)); v = fmaxf(v, dpp_f<0x122>(v, v)); v = fmaxf(v, dpp_f<0x121>(v, v));
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d, 16);
+    v += dpp_f<0x128>(v, v); v += dpp_f<0x124>(v, v); v += dpp_f<0x122>(v, v); v += dpp_f<0x121>(v, v);
+    return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, dpp_i<0x128>(v, v)); v = min(v, dpp_i<0x124>(v, v)); v = min(v, dpp_i<0x122>(v, v)); v = min(v, dpp_i<0x121>(v, v));
+    return v;
+}
+__device__ __forceinline__ int row16_isum(int v) {
+    v += dpp_i<0x128>(v, v); v += dpp_i<0x124>(v, v); v += dpp_i<0x122>(v, v); v += dpp_i<0x121>(v, v);
+    return v;
+}
+__device__ __forceinline__ float row16_scan(float v) {   // inclusive prefix sum along the row
+    v += dpp_f<0x111>(v, 0.0f); v += dpp_f<0x112>(v, 0.0f); v += dpp_f<0x114>(v, 0.0f); v += dpp_f<0x118>(v, 0.0f);
     return v;
 }
 
-template <int PER>
+template <int PER, bool DET>
 __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, const float *mask, int64_t *action,
                                                          float *log_prob, int E, int M, int64_t env_id_base,
-                                                         uint64_t seed, uint64_t step, int deterministic) {
+                                                         uint64_t seed, uint64_t step) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid >> 4, sl = threadIdx.x & 15;
     const bool active = e < E;
     const size_t row = (size_t)(active ? e : 0) * M;
     const float4 *xq = (const float4 *)(logits + row), *mq = (const float4 *)(mask + row);
     const int nq = M >> 2;
-    // lane sl owns quads sl, sl+16, sl+32, ...: every load instruction of the 16-lane row is one
-    // contiguous 256-byte segment
-    float z[PER][4];
+    float4 xv[PER], mv[PER];
     bool in[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {      // every load of both operands is issued before any arithmetic
+        const int qi = sl + 16 * k;
+        in[k] = qi < nq;
+        // a quad past the end of the row behaves like four entries that can never be chosen: logit -inf (probability 0 before
+        // the floor), and the 1e-5 floor itself is switched off for it below
+        xv[k] = in[k] ? xq[qi] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        mv[k] = in[k] ? mq[qi] : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    float z[PER][4];
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int qi = sl + 16 * k;
-        in[k] = qi < nq;
-        const float4 x = in[k] ? xq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 m = in[k] ? mq[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-        z[k][0] = x.x - (1.0f - m.x) * 14.0f;  // distributions.py:76-79
-        z[k][1] = x.y - (1.0f - m.y) * 14.0f;
-        z[k][2] = x.z - (1.0f - m.z) * 14.0f;
-        z[k][3] = x.w - (1.0f - m.w) * 14.0f;
-        if (in[k]) mx = fmaxf(fmaxf(mx, fmaxf(z[k][0], z[k][1])), fmaxf(z[k][2], z[k][3]));
+        z[k][0] = xv[k].x - (1.0f - mv[k].x) * 14.0f;  // distributions.py:76-79
+        z[k][1] = xv[k].y - (1.0f - mv[k].y) * 14.0f;
+        z[k][2] = xv[k].z - (1.0f - mv[k].z) * 14.0f;
+        z[k][3] = xv[k].w - (1.0f - mv[k].w) * 14.0f;
+        mx = fmaxf(fmaxf(mx, fmaxf(z[k][0], z[k][1])), fmaxf(z[k][2], z[k][3]));
     }
     mx = row16_max(mx);
+    const float mxl = mx * 1.44269504088896340736f;
     float part = 0.0f;
 #pragma unroll
     for (int k = 0; k < PER; ++k)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            z[k][t] = in[k] ? __expf(z[k][t] - mx) : 0.0f;
+            z[k][t] = __builtin_amdgcn_exp2f(z[k][t] * 1.44269504088896340736f - mxl);   // exp(z - mx); exp2(-inf) = 0
             part += z[k][t];
         }
-    const float sum = row16_sum(part);
-    const float inv_sum = 1.0f / sum;
+    const float inv_sum = __builtin_amdgcn_rcpf(row16_sum(part));
     float qtot[PER];
-    float lane_tot = 0.0f, best = -1.0f;
-    int best_i = 0;
+    float lane_tot = 0.0f;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
+        const float floor_k = in[k] ? 1e-5f : 0.0f;       // distributions.py:79-80
         qtot[k] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float pk = in[k] ? z[k][t] * inv_sum + 1e-5f : 0.0f;  // distributions.py:79-80
-            z[k][t] = pk;
-            qtot[k] += pk;
-            if (in[k] && pk > best) {
-                best = pk;
-                best_i = (sl + 16 * k) * 4 + t;
-            }
+            z[k][t] = z[k][t] * inv_sum + floor_k;
+            qtot[k] += z[k][t];
         }
         lane_tot += qtot[k];
     }
     const float tot = row16_sum(lane_tot);
     int a;
-    float pa;
-    if (deterministic) {  // dist.mode(): first index of the maximum
+    if constexpr (DET) {     // dist.mode(): first index of the maximum
+        float best = -1.0f;
+        int best_i = 0;
 #pragma unroll
-        for (int d = 8; d > 0; d >>= 1) {
-            const float ob = __shfl_xor(best, d, 16);
-            const int oi = __shfl_xor(best_i, d, 16);
-            if (ob > best || (ob == best && oi < best_i)) {
-                best = ob;
-                best_i = oi;
-            }
-        }
-        a = best_i;
-        pa = best;
-    } else {  // inverse CDF at u * total, entries taken in index order (quad-row k, then lane)
+        for (int k = 0; k < PER; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (z[k][t] > best) {
+                    best = z[k][t];
+                    best_i = (sl + 16 * k) * 4 + t;
+                }
+        const float rb = row16_max(best);
+        a = row16_min(best == rb ? best_i : 0x7fffffff);
+    } else {
+        // inverse CDF at u * total, entries in index order (quad-row k, then lane): the chosen entry is the first one whose
+        // inclusive cumulative sum exceeds the target = the NUMBER of entries whose cumulative sum does not (the sums of a
+        // lane grow with the index; the handful of cases where float32 rounding makes a lane's start fall an ulp below its
+        // predecessor's end move a draw by one entry whose cumulative sum equals the target to ~1e-7 -- inside the CDF
+        // tolerance the kernel is held to)
         const float u = (float)(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + (active ? e : 0))) >> 8) * (1.0f / 16777216.0f);
         const float target = u * tot;
-        float base = 0.0f, pm = 0.0f;
-        int cand = 0x7fffffff;
+        float base = 0.0f;
+        int below = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            float incl = qtot[k];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const float o = __shfl_up(incl, d, 16);
-                if (sl >= d) incl += o;
-            }
+            const float incl = row16_scan(qtot[k]);
             float c = base + incl - qtot[k];
+            int bk = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 c += z[k][t];
-                if (cand == 0x7fffffff && in[k] && c > target) {
-                    cand = (sl + 16 * k) * 4 + t;
-                    pm = z[k][t];
-                }
+                bk += c <= target ? 1 : 0;
             }
-            base += __shfl(incl, 15, 16);
+            below += in[k] ? bk : 0;
+            if (k + 1 < PER) base += row16_sum(qtot[k]);
         }
-        // the lowest index that crossed the target wins; none -> last entry (rounding at u ~ 1)
-#pragma unroll
-        for (int d = 8; d > 0; d >>= 1) {
-            const int oc = __shfl_xor(cand, d, 16);
-            const float op = __shfl_xor(pm, d, 16);
-            if (oc < cand) {
-                cand = oc;
-                pm = op;
-            }
-        }
-        if (cand == 0x7fffffff) {
-            cand = M - 1;
-            const int lq = (M - 1) >> 2, ll = lq & 15, lk = lq >> 4;
-            float lastp = 0.0f;
-#pragma unroll
-            for (int k = 0; k < PER; ++k)
-                if (k == lk) lastp = z[k][(M - 1) & 3];
-            pm = __shfl(lastp, ll, 16);
-        }
-        a = cand;
-        pa = pm;
+        a = min(row16_isum(below), M - 1);          // (every sum <= target: rounding at u ~ 1 -> last entry)
     }
-    if (active && sl == 0) {
+    // the lane that owns entry `a` holds its probability: it writes both outputs
+    const int aq = a >> 2;
+    if (active && (aq & 15) == sl) {
+        float pa = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if ((aq >> 4) == k) {
+                const int t = a & 3;
+                pa = t == 0 ? z[k][0] : (t == 1 ? z[k][1] : (t == 2 ? z[k][2] : z[k][3]));
+            }
         action[e] = a;
         if (log_prob) {
             const float eps = 1.1920928955078125e-7f;  // torch clamp_probs: finfo(float32).eps
-            log_prob[e] = logf(fminf(fmaxf(pa / tot, eps), 1.0f - eps));
+            log_prob[e] = __logf(fminf(fmaxf(pa * __builtin_amdgcn_rcpf(tot), eps), 1.0f - eps));
         }
     }
 }
@@ -2633,7 +2647,13 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
     }
     const int per = (M / 4 + 15) / 16;
     const int blocks = (E + 15) / 16;
-#define BPP_ACT(P) hipLaunchKernelGGL(masked_act_kernel<P>, dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step, deterministic)
+#define BPP_ACT(P)                                                                                                                     \
+    do {                                                                                                                               \
+        if (deterministic)                                                                                                             \
+            hipLaunchKernelGGL((masked_act_kernel<P, true>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step); \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((masked_act_kernel<P, false>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step); \
+    } while (0)
     switch (per) {
         case 1: BPP_ACT(1); break;
         case 2: BPP_ACT(2); break;

@@ -152,8 +152,25 @@ static inline T shfl_xor(T v, int m, int width, int line) {
     const int l = lane_id(), base = l & ~(width - 1), s = l ^ m;
     return shfl(v, (s < base || s >= base + width) ? l : s, line);
 }
+// DPP (v_mov_b32_dpp): row_shl / row_shr / row_ror within a row of 16 lanes and quad_perm; a lane without a source reads 0
+// with bound_ctrl, else keeps `old`.  Every lane of the wave executes the instruction (the kernels use it with all lanes on).
+static inline int dpp(int old, int src, int ctrl, bool bound_ctrl, int line) {
+    const int l = lane_id(), row = l & ~15, p = l & 15;
+    int s;
+    if (ctrl >= 0x101 && ctrl <= 0x10f) s = p + (ctrl - 0x100) <= 15 ? row + p + (ctrl - 0x100) : -1;        // row_shl:n  lane p reads p + n
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) s = p - (ctrl - 0x110) >= 0 ? row + p - (ctrl - 0x110) : -1;    // row_shr:n  lane p reads p - n
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) s = row + ((p - (ctrl - 0x120)) & 15);                         // row_ror:n  lane p reads (p - n) mod 16
+    else if (ctrl >= 0 && ctrl < 0x100) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);                       // quad_perm
+    else abort();
+    const int got = shfl(src, s < 0 ? l : s, line);
+    return s < 0 ? (bound_ctrl ? 0 : old) : got;
+}
 }  // namespace emu
 
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) emu::dpp((old), (src), (ctrl), (bound_ctrl), __LINE__)
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+#define __logf(x) logf(x)
 #define threadIdx (emu::g_threadIdx)
 #define blockIdx (emu::g_blockIdx)
 #define blockDim (emu::g_blockDim)
