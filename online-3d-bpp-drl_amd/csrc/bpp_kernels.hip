@@ -2122,9 +2122,14 @@ struct Launch {
 // per wave.  Any other bin with W*L % 4 == 0 and H <= 22 -- and these, when the launch-shape knobs are set --
 // runs bpp_fast_kernel with runtime geometry.
 struct TileGeoEntry {
-    int W, L, K, epw, nit, nit_big;   // groups per wave of the step kernel: default / when the outputs of one
-};                                    // launch exceed the 256 MiB Infinity Cache (measured)
-constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1, 2}, {20, 20, 1, 1, 1, 4}, {20, 20, 2, 1, 1, 4}, {10, 10, 2, 4, 1, 2}};
+    int W, L, K, epw, nit, nit_big, nit_big_rot;   // groups per wave of the step kernel: default / when the outputs of one launch
+};                                                 // exceed the 256 MiB Infinity Cache, without / with rotation (measured)
+// Round 6 (profiles/r6e_sweep_bins_by_tile_groups_*.txt, two boxes): with ONE group per wave a launch of 262 144 / 1 048 576 10x10 bins
+// costs 14 - 17 % more per bin than a 65 536-bin launch (146 - 152 us instead of 4 x 31.8; eight and more rounds of workgroups: the
+// later rounds' cold reads queue behind the earlier rounds' write streams), with two or four groups per wave it does not (128 - 132 /
+// 124 - 132 us; 1 048 576 bins: 477 - 494 / 466 - 475 us = 2.1 - 2.25 G env steps/s) -- fewer, longer workgroups whose loads all
+// go out before any of their stores.  With rotation two groups win (155 vs 162 us with four, 175 with one).
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1, 4, 2}, {20, 20, 1, 1, 1, 4, 4}, {20, 20, 2, 1, 1, 4, 4}, {10, 10, 2, 4, 1, 2, 2}};
 constexpr size_t kOutputsPastL3 = 300u * 1000u * 1000u;   // obs + mask bytes per launch
 constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
@@ -2233,7 +2238,7 @@ Launch configure(int E, int W, int L, int H, int rotation, int rule) {
     if (l.tile >= 0) {   // the tile kernel's launch shape is part of its type; only the grid depends on E
         const bool past_l3 = (size_t)E * (size_t)(16 * p.A + 4 * p.M) > kOutputsPastL3;
         l.nit = (kn.tile_groups == 1 || kn.tile_groups == 2 || kn.tile_groups == 4)
-                    ? kn.tile_groups : (past_l3 ? kTileGeo[l.tile].nit_big : kTileGeo[l.tile].nit);
+                    ? kn.tile_groups : (past_l3 ? (rotation ? kTileGeo[l.tile].nit_big_rot : kTileGeo[l.tile].nit_big) : kTileGeo[l.tile].nit);
         const int nb = kTileWaves * kTileGeo[l.tile].epw * l.nit;   // step kernel; reset / mask kernels: one group
         p.epw = kTileGeo[l.tile].epw;
         l.wpb = kTileWaves;

@@ -56,7 +56,8 @@ done
 BPP_BENCH_ONE_DEVICE=1 timeout 300 python bench.py --gpus 2 --steps 100 --warmup 20 --gpu-seconds 1 --only-headline 2> $O/bench_2ranks.err | tail -n 1 > $O/bench_2ranks_self_launched_one_device.json
 BPP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 8 --envs 8192 --steps 20 --warmup 5 --gpu-seconds 0.3 --no-past-l3 2> $O/bench_8ranks.err | tail -n 1 > $O/bench_8ranks_self_launched_one_device_8192_bins_each.json
 BPP_BENCH_FORCE_PG=1 timeout 300 python bench.py --no-cpu-baseline --only-headline --steps 100 --warmup 20 --gpu-seconds 1 2> $O/bench_rccl_world1.err | head -n 1 > $O/bench_rccl_world1.json
-timeout 600 python tools/sweep_bins.py --bins 65536 262144 > $O/sweep_bins_10.jsonl 2> $O/sweep.err
+timeout 600 python tools/sweep_bins.py --bins 65536 262144 1048576 > $O/sweep_bins_10.jsonl 2> $O/sweep.err      # (a fresh process: late in a long script the same launches measured 10 % slower at 262 144 bins -- see profiles/README.md, r6e)
+timeout 600 python tools/sweep_bins.py --rotation --bins 65536 262144 > $O/sweep_bins_10_rot.jsonl 2>> $O/sweep.err
 for f in bench_steps20 bench bench_rotation bench_20x20x20 bench_primary_pool_cut2_dataset; do
   python - <<PY
 import json
