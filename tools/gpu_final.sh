@@ -31,9 +31,9 @@ for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768 --pool 2048
   BENCH_EXTRA="--no-past-l3 --reps 3" tools/profile_pmc.sh ${TAG}_$name $args > /dev/null 2>&1
   cp $R/gpurun_out/pmc_${TAG}_$name/summary.txt $O/pmc_summary_$name.txt 2>/dev/null
 done
-python tools/pmc_to_json.py 10x10x10_rot0_E65536=$O/pmc_summary_10.txt 10x10x10_rot1_E65536=$O/pmc_summary_10rot.txt \
+python tools/pmc_to_json.py --tracked-prefix profiles/${TAG}_ 10x10x10_rot0_E65536=$O/pmc_summary_10.txt 10x10x10_rot1_E65536=$O/pmc_summary_10rot.txt \
     20x20x20_rot0_E32768=$O/pmc_summary_20.txt > /dev/null 2>> $O/bench.err
-cp profiles/hbm_traffic.json $O/hbm_traffic.json
+cp profiles/hbm_traffic.json $O/hbm_traffic.json; cp profiles/${TAG}_pmc_summary_*.txt $O/ 2>/dev/null      # (profiles/ itself does not travel back: gpurun merges gpurun_out/ only)
 python tools/bench_mask_kernels.py > $O/mask_and_reset_kernels.json 2>> $O/bench.err
 python tools/bench_dropin_step.py > $O/dropin_step.json 2>> $O/bench.err
 python tools/bench_acc_reduce.py > $O/acc_reduce.json 2>> $O/bench.err

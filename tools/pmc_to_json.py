@@ -2,7 +2,10 @@
 """Fold rocprofv3 PMC summaries (tools/profile_pmc.sh -> summary.txt) into profiles/hbm_traffic.json, the file
 bench.py reads `roofline.traffic` / `frac_moved` / `limiter` from.
 
-    python tools/pmc_to_json.py <key>=<summary.txt> [...]     e.g. 10x10x10_rot0_E65536=profiles/r02a_pmc_summary_10.txt
+    python tools/pmc_to_json.py [--tracked-prefix profiles/r6_] <key>=<summary.txt> [...]     e.g. 10x10x10_rot0_E65536=gpurun_out/x/pmc_summary_10.txt
+
+--tracked-prefix P: every summary is first COPIED to <P>pmc_summary_<10|10rot|20...>.txt (a tracked file under profiles/) and that
+copy is what the JSON names as its `source` (the source used to be a scratch path under gpurun_out/).
 
 Counter handling (MI355X_MICROARCH.md "HBM", calibrated on this box with tools/ubench calib, profiles/r02a_counter_calibration.txt):
   * FETCH_SIZE and WRITE_SIZE are in KiB and come from separate passes;
@@ -44,10 +47,21 @@ def main():
                        "traffic_bytes = WRITE_SIZE KiB * 1024 + 2 * FETCH_SIZE KiB * 1024 (FETCH_SIZE reports half of the bytes "
                        "read on gfx950, WRITE_SIZE is exact; calibrated with tools/ubench calib); valu_utilisation = "
                        "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32)")
-    for arg in sys.argv[1:]:
+    args = sys.argv[1:]
+    prefix = None
+    if args and args[0] == "--tracked-prefix":
+        prefix, args = args[1], args[2:]
+    for arg in args:
         key, path = arg.split("=", 1)
-        c = parse(path)
         dims, rot, envs = key.split("_")
+        if prefix:
+            import shutil
+            side = dims.split("x")[0]
+            tracked = os.path.join(ROOT, "%spmc_summary_%s%s.txt" % (prefix, side, "rot" if rot == "rot1" else ""))
+            if os.path.abspath(path) != os.path.abspath(tracked):
+                shutil.copyfile(path, tracked)
+            path = tracked
+        c = parse(path)
         W, L, H = (int(v) for v in dims.split("x"))
         E = int(envs[1:])
         contiguous = E * (W * L + 48 + 8 + 32)       # byte tile, state record, action, ep_acc row (prefetched for every bin)
