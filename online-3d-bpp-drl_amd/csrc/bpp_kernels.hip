@@ -283,7 +283,7 @@ struct __attribute__((aligned(16))) BinRec {
 
 // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: block b runs on XCD (b + c) % 8, where the
 // offset c is the same for all blocks of a launch but not always the same from launch to launch (tools/xcc_map.hip,
-// profiles/r03g_xcc_map.jsonl: 7 for a process's first launch, 6 afterwards).  Give every XCD one contiguous eighth of
+// profiles/archive/r03g_xcc_map.jsonl: 7 for a process's first launch, 6 afterwards).  Give every XCD one contiguous eighth of
 // the bins so that cache lines shared by neighbouring waves (the small per-bin outputs, the byte heightmaps) are
 // completed inside ONE L2 instead of being written back as partial lines from several.  Bijective for any grid size;
 // affects speed only.

@@ -34,7 +34,7 @@ constexpr CandMagicTable make_cand_magic() {
 __constant__ const CandMagicTable kCandMagic = make_cand_magic();
 
 constexpr int kTileWaves = 4;  // waves per workgroup of the tile kernel
-// Where a finishing bin's episode-accumulator row is read and written back (A/B of round 3, profiles/r3x_ab_r3aa.txt;
+// Where a finishing bin's episode-accumulator row is read and written back (A/B of round 3, profiles/archive/r3x_ab_r3aa.txt;
 // the rejected forms live there, not here).  kAccLate (a wave owns several bins): every bin reads its row up front with
 // the state record AS A PREFETCH (the values are dead unless the bin finishes), the finishing bins read it again behind
 // the second barrier -- now a cache hit -- and add / store it at the END of the kernel: 10x10 past the Infinity Cache

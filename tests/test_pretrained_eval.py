@@ -109,6 +109,49 @@ def test_hip_replays_all_2100_trajectories(bpp, case, rot, ckpt, path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_hip_full_size_launch_in_deep_states_every_bin(bpp, oracle, case, rot, ckpt):
+    """BASELINE config 2 / 3's launch -- 65 536 bins -- driven for 44 lock-steps by the reference's own checkpoint (the actor
+    rebuilt from plain torch layers on the device, bpp_masked_act's mode), EVERY bin compared with the oracle stepping the
+    same 65 536 bins with the same actions: observation, mask, reward, done, counter, ratio, episode return / length, finally
+    the heightmaps.  The every-bin tests of tests/test_gpu_parity.py draw uniform-feasible actions (episodes ~8 boxes deep);
+    here ~1 env-step in 6 is on a bin that already holds >= 16 boxes and bins are packed completely at full launch size."""
+    import sys
+    import torch
+    from oracle import ref_shims
+    if not ref_shims.copy_available() or not os.path.isfile(os.path.join(ref_shims.REF_COPY, "pretrained_models", ckpt)):
+        pytest.skip("oracle/_ref/ without the checkpoints (python oracle/make_ref.py)")
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import evaluate_checkpoint as ev
+    size, E, steps = (10, 10, 10), 65536, 44
+    pool = bpp.sequences.from_dataset(os.path.join(ROOT, "tests", "golden", "cut2_dataset_10.npz"), size)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool)
+    ref = oracle.OracleEnv(pool, size, rot, E)
+    actor = ev.load_actor(os.path.join(ref_shims.REF_COPY, "pretrained_models", ckpt), 10, env.action_space.n, env.device)
+    obs = env.reset()
+    robs, rmask = ref.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), robs)
+    mask = env.location_masks
+    deep = full = episodes = 0
+    for t in range(steps):
+        with torch.no_grad():
+            logits = actor(obs).float()
+        action, _ = bpp.masked_act(logits, mask, deterministic=True)
+        r = env.step_tensors(action)
+        o = ref.step(action.cpu().numpy().reshape(-1), copy=False)
+        for k in ("obs", "mask", "done", "counter", "ratio", "ep_ret", "ep_len"):
+            np.testing.assert_array_equal(getattr(r, k).cpu().numpy().reshape(o[k].shape), o[k], err_msg="%s at lock-step %d" % (k, t))
+        np.testing.assert_array_equal(r.reward.cpu().numpy()[:, 0], o["reward"], err_msg="reward at lock-step %d" % t)
+        obs, mask = r.obs, r.mask
+        deep += int((o["counter"] >= 16).sum())
+        d = o["done"] != 0
+        full += int((d & (o["ratio"] == 1.0)).sum())
+        episodes += int(d.sum())
+    np.testing.assert_array_equal(env.hmap.cpu().numpy(), ref.hmap)
+    assert deep >= 0.08 * E * steps and full >= 50 and episodes >= 1.5 * E, (deep / float(E * steps), full, episodes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
 def test_consumer_evaluation_of_the_reference_checkpoint(bpp, case, rot, ckpt):
     """examples/evaluate_checkpoint.py on the GPU box: checkpoint and dataset from oracle/_ref/ (byte-for-byte copies of the
     reference's files, oracle/make_ref.py) -- DATA files only; no reference code runs here."""

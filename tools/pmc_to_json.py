@@ -7,7 +7,7 @@ bench.py reads `roofline.traffic` / `frac_moved` / `limiter` from.
 --tracked-prefix P: every summary is first COPIED to <P>pmc_summary_<10|10rot|20...>.txt (a tracked file under profiles/) and that
 copy is what the JSON names as its `source` (the source used to be a scratch path under gpurun_out/).
 
-Counter handling (MI355X_MICROARCH.md "HBM", calibrated on this box with tools/ubench calib, profiles/r02a_counter_calibration.txt):
+Counter handling (MI355X_MICROARCH.md "HBM", calibrated on this box with tools/ubench calib, profiles/archive/r02a_counter_calibration.txt):
   * FETCH_SIZE and WRITE_SIZE are in KiB and come from separate passes;
   * FETCH_SIZE reports exactly HALF of the bytes read, for 4-byte-per-lane and 16-byte-per-lane loads alike
     (1 GiB read -> 524 298 KiB) -> doubled;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stress the episode statistics (GPU box).  Rounds 1-2 added finished episodes into 256 shared slots with float64
 L2 atomics (slot = workgroup index >> 3); one GPU-suite run lost 0.05 - 0.7 % of those adds while every per-bin output
-stayed bit-exact (profiles/r03f_pytest_gpu.log).  The product now keeps one accumulator row per bin (plain
+stayed bit-exact (profiles/archive/r03f_pytest_gpu.log).  The product now keeps one accumulator row per bin (plain
 read-modify-write by the bin's own lane, fixed-order reduction) -- exact by construction.  This tool
 
   * runs >= --launches lock-steps over alternating env objects (so buffers come and go through the caching allocator),
@@ -9,7 +9,7 @@ read-modify-write by the bin's own lane, fixed-order reduction) -- exact by cons
   * after every chunk compares the per-bin rows and their fixed-order reduction with the ORACLE bit for bit
     (assert_array_equal) -- the exactness claim of the new path;
   * (round 3 only: a diagnostic build that kept the OLD slotted atomics beside the rows was compared as well --
-    profiles/r3_stress_stats_legacy_atomics.json: 20 000 launches, no add lost; that switch has since been removed from
+    profiles/archive/r3_stress_stats_legacy_atomics.json: 20 000 launches, no add lost; that switch has since been removed from
     the source, commit c585660 has it.  The `legacy` branches below only act when a library exports
     bpp_debug_legacy_slots.)
 
