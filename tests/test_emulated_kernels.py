@@ -38,7 +38,8 @@ GEOMS = [((10, 10, 10), False, 150, 11), ((10, 10, 10), True, 90, 12), ((20, 20,
          ((7, 13, 8), True, 33, 14), ((5, 4, 6), False, 37, 15), ((32, 32, 40), True, 3, 16),
          ((20, 20, 10), True, 13, 17), ((20, 20, 22), True, 9, 18), ((10, 10, 11), False, 20, 20),
          ((2, 2, 5), True, 20, 21), ((1, 3, 4), False, 13, 22), ((1, 1, 3), True, 7, 24),
-         ((8, 128, 10), True, 5, 25), ((4, 255, 10), False, 5, 26), ((14, 72, 12), True, 3, 27), ((12, 81, 9), False, 3, 28)]
+         ((8, 128, 10), True, 5, 25), ((4, 255, 10), False, 5, 26), ((14, 72, 12), True, 3, 27), ((12, 81, 9), False, 3, 28),
+         ((10, 10, 30), True, 19, 29), ((12, 8, 46), False, 11, 30), ((10, 10, 47), False, 7, 31)]     # four histogram words (H <= 46); 47: cell scan
 
 
 @pytest.mark.parametrize("size,rot,E,seed", GEOMS)

@@ -90,7 +90,8 @@ GEOMS = [((10, 10, 10), False, 1024, 11), ((10, 10, 10), True, 1000, 12), ((20, 
          ((7, 13, 8), True, 333, 14), ((5, 4, 6), False, 77, 15), ((32, 32, 40), True, 9, 16),
          ((20, 20, 10), True, 130, 17), ((20, 20, 22), True, 67, 18), ((10, 10, 7), True, 203, 19),
          ((10, 10, 11), False, 50, 20), ((2, 2, 5), True, 40, 21), ((1, 3, 4), False, 33, 22), ((3, 1, 4), True, 20, 23),
-         ((1, 1, 3), True, 17, 24), ((8, 128, 10), True, 50, 25), ((4, 255, 10), False, 40, 26), ((14, 72, 12), True, 9, 27)]
+         ((1, 1, 3), True, 17, 24), ((8, 128, 10), True, 50, 25), ((4, 255, 10), False, 40, 26), ((14, 72, 12), True, 9, 27),
+         ((10, 10, 30), True, 300, 28), ((12, 8, 46), False, 90, 29), ((10, 10, 47), False, 40, 30)]      # K = 4 (round 6); H = 47: cell scan
 
 
 @pytest.mark.parametrize("size,rot,E,seed", GEOMS)
