@@ -8,6 +8,12 @@ this package: observations and masks from BppVecEnv.step_tensors, action selecti
 Nothing leaves the GPU until the summary is printed.
 
     python examples/rollout_with_policy.py --envs 16384 --steps 200
+    python examples/rollout_with_policy.py --envs 64 --steps 2000 --graph      # the reference's scale: one HIP-graph launch per lock-step
+
+--graph: policy forward + bpp_masked_act_counter + the fused environment step + the step counter's increment are captured ONCE
+in a HIP graph (torch.cuda.CUDAGraph) and replayed: at 16 ... 1 024 bins a lock-step is ~25 kernel launches of a few
+microseconds each, i.e. launch-bound; the graph turns them into one launch.  The sampler's (seed, step) live in device memory
+(`counter`), so every replay draws afresh.
 """
 import argparse
 import os
@@ -45,12 +51,15 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--rotation", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="run the policy under bf16 autocast")
+    ap.add_argument("--graph", action="store_true", help="capture one lock-step (policy, masked_act, env step) in a HIP graph and replay it")
     ap.add_argument("--stream", action="store_true",
                     help="endless item supply generated on the device (every bin its own random.Random, nothing replayed) "
                          "instead of a pool of 4096 sequences")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     size = (10, 10, 10)
+    if args.graph and args.stream:
+        raise SystemExit("--graph replays ONE captured lock-step; the stream supply's refills are scheduled by host code between lock-steps")
     if args.stream:
         envs = bpp_amd.BppVecEnv(args.envs, size, enable_rotation=args.rotation, device=dev,
                                  stream=dict(bound=(2, 5), seed=0, depth=16, refill_every=8))
@@ -62,22 +71,41 @@ def main():
     masks = envs.location_masks
     stats = bpp_amd.EpisodeStats(dev)
 
-    def one_step(t):
-        nonlocal obs, masks
+    counter = torch.tensor([7, 0], dtype=torch.int64, device=dev)                 # (seed, step) of the sampler, read by the kernel
+    act_out = (torch.empty((args.envs, 1), dtype=torch.int64, device=dev), torch.empty((args.envs, 1), dtype=torch.float32, device=dev))
+
+    def one_step(t=None):
+        # obs / masks are the env's own output buffers (fresh_outputs=False): the same tensors every lock-step
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
             logits = policy(obs)
-        action, logp = bpp_amd.masked_act(logits.float(), masks, seed=7, step=t)
+        action, logp = bpp_amd.masked_act(logits.float(), masks, counter=counter, out=act_out)
         res = envs.step_tensors(action)
-        obs, masks = res.obs, res.mask
+        counter[1:].add_(1)
         return res
 
     for t in range(10):
-        one_step(t)
+        one_step()
+    graph = None
+    if args.graph:
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # (warm-up on a side stream, as torch's graph recipe asks)
+            for t in range(3):
+                one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
     envs.episode_stats(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(10 + t)
+    if graph is not None:
+        for t in range(args.steps):
+            graph.replay()
+    else:
+        for t in range(args.steps):
+            one_step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s = stats.collect(envs).summary()
@@ -89,9 +117,9 @@ def main():
         envs.step_tensors(a, sample=(1, t + 1, a))
     torch.cuda.synchronize()
     dt_env = time.perf_counter() - t1
-    print("policy in the loop: %.2f M env steps/s (%.1f us per lock-step of %d bins); environment alone %.1f us; "
+    print("policy in the loop%s: %.2f M env steps/s (%.1f us per lock-step of %d bins); environment alone %.1f us; "
           "episodes %d, mean space utilisation %.3f, mean length %.1f"
-          % (args.envs * args.steps / dt / 1e6, dt / args.steps * 1e6, args.envs, dt_env / args.steps * 1e6,
+          % (" (ONE HIP-graph launch per lock-step)" if graph is not None else "", args.envs * args.steps / dt / 1e6, dt / args.steps * 1e6, args.envs, dt_env / args.steps * 1e6,
              s["episodes"], s["mean_ratio"], s["mean_length"]))
 
 

@@ -312,6 +312,13 @@ int bpp_epsilon_override(int64_t *actions, int32_t E, int32_t M, int64_t env_id_
  * float32 arithmetic; logits, mask: [E][M] float32; action: [E] int64; log_prob: [E] float32 (may be NULL). */
 int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
                    int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream);
+/* The same selection with (seed, step) read from DEVICE memory -- seed_step: uint64 [2] -- when the kernel runs (v16).  For loops
+ * captured in a HIP graph: a captured launch replays its arguments, so a `step` passed by value would give every replay the same
+ * draws; here the caller advances seed_step[1] on the device between two replays (one more node of the same graph, e.g. a torch
+ * `add_`) and every replay draws afresh.  At the reference's own scale (16 ... 1 024 bins) a policy step is launch-bound -- ~25
+ * launches of a few microseconds each -- and one graph launch replaces them (examples/rollout_with_policy.py --graph). */
+int bpp_masked_act_counter(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                           int64_t env_id_base, const uint64_t *seed_step, int32_t deterministic, void *stream);
 
 /* Training half of the same head (acktr/distributions.py:71-101 as consumed by Policy.evaluate_actions,
  * acktr/model.py:90-96), forward and backward, float32:

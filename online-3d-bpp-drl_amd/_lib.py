@@ -27,7 +27,7 @@ REDUCE_SCRATCH_BYTES = REDUCE_LANES * 4 * 8 + 64
 SYMBOLS = ["bpp_abi_version", "bpp_last_error", "bpp_limits", "bpp_reset", "bpp_step", "bpp_mask_from_obs",
            "bpp_mask_from_hmap", "bpp_sample_feasible", "bpp_episode_stats", "bpp_rollout_uniform", "bpp_masked_act", "bpp_gen_cut2", "bpp_gen_cut1", "bpp_gen_rs",
            "bpp_get_knobs", "bpp_set_knobs", "bpp_launch_info", "bpp_stream_sizes", "bpp_stream_init", "bpp_stream_refill",
-           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override", "bpp_side_create", "bpp_side_destroy", "bpp_mark", "bpp_wait_mark", "bpp_step_dropin"]
+           "bpp_rollout_uniform_stream", "bpp_masked_evaluate", "bpp_masked_evaluate_backward", "bpp_episode_acc_reduce", "bpp_rollout_uniform_sets", "bpp_fetch_to_host", "bpp_wait", "bpp_gather_finished", "bpp_epsilon_override", "bpp_side_create", "bpp_side_destroy", "bpp_mark", "bpp_wait_mark", "bpp_step_dropin", "bpp_masked_act_counter"]
 
 
 class Batch(ctypes.Structure):
@@ -160,6 +160,8 @@ def lib():
         L.bpp_wait.argtypes = [ctypes.c_void_p]
         L.bpp_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_wait_mark.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.bpp_masked_act_counter.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_int32, ctypes.c_void_p]
         L.bpp_step_dropin.argtypes = [ctypes.POINTER(Batch), ctypes.c_void_p, ctypes.POINTER(StepOut), ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_gather_finished.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]

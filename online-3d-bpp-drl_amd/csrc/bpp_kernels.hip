@@ -1484,7 +1484,8 @@ __device__ __forceinline__ float row16_scan(float v) {   // inclusive prefix sum
 template <int PER, bool DET>
 __global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, const float *mask, int64_t *action,
                                                          float *log_prob, int E, int M, int64_t env_id_base,
-                                                         uint64_t seed, uint64_t step) {
+                                                         uint64_t seed, uint64_t step, const uint64_t *seed_step) {
+    if (seed_step != nullptr) seed = seed_step[0], step = seed_step[1];   // bpp_masked_act_counter: (seed, step) live in device memory
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid >> 4, sl = threadIdx.x & 15;
     const bool active = e < E;
@@ -1604,7 +1605,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 __global__ __launch_bounds__(256) void masked_act_kernel_generic(const float *logits, const float *mask, int64_t *action,
                                                                  float *log_prob, int E, int M, int64_t env_id_base,
-                                                                 uint64_t seed, uint64_t step, int deterministic) {
+                                                                 uint64_t seed, uint64_t step, int deterministic, const uint64_t *seed_step) {
+    if (seed_step != nullptr) seed = seed_step[0], step = seed_step[1];
     const int lane = threadIdx.x & (kWave - 1);
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;  // whole waves leave; no block-level synchronisation below
@@ -2639,14 +2641,17 @@ int bpp_gen_rs(uint8_t *pool, int32_t n, int32_t T, int32_t W, int32_t L, int32_
     return 0;
 }
 
-int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
-                   int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream) {
-    if (!logits || !mask || !action) return fail(BPP_E_BADARG, "bpp_masked_act: NULL pointer");
-    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, "bpp_masked_act: non-positive size");
+}  // extern "C"
+
+namespace {
+int masked_act_launch(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M, int64_t env_id_base,
+                      uint64_t seed, uint64_t step, const uint64_t *seed_step, int32_t deterministic, void *stream, const char *who) {
+    if (!logits || !mask || !action) return fail(BPP_E_BADARG, who);
+    if (E <= 0 || M <= 0) return fail(BPP_E_BADARG, who);
     hipStream_t st = (hipStream_t)stream;
     if (M % 4 != 0 || M > 16 * 8 * 4 || !aligned16(logits) || !aligned16(mask)) {  // wave-per-bin kernel: any M, any alignment
         hipLaunchKernelGGL(masked_act_kernel_generic, dim3((E + 3) / 4), dim3(256), 0, st, logits, mask, action, log_prob, E, M,
-                           env_id_base, seed, step, deterministic);
+                           env_id_base, seed, step, deterministic, seed_step);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
     }
@@ -2655,9 +2660,9 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
 #define BPP_ACT(P)                                                                                                                     \
     do {                                                                                                                               \
         if (deterministic)                                                                                                             \
-            hipLaunchKernelGGL((masked_act_kernel<P, true>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step); \
+            hipLaunchKernelGGL((masked_act_kernel<P, true>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step, seed_step); \
         else                                                                                                                           \
-            hipLaunchKernelGGL((masked_act_kernel<P, false>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step); \
+            hipLaunchKernelGGL((masked_act_kernel<P, false>), dim3(blocks), dim3(256), 0, st, logits, mask, action, log_prob, E, M, env_id_base, seed, step, seed_step); \
     } while (0)
     switch (per) {
         case 1: BPP_ACT(1); break;
@@ -2670,6 +2675,22 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
 #undef BPP_ACT
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+}  // namespace
+
+extern "C" {
+
+int bpp_masked_act(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                   int64_t env_id_base, uint64_t seed, uint64_t step, int32_t deterministic, void *stream) {
+    return masked_act_launch(logits, mask, action, log_prob, E, M, env_id_base, seed, step, nullptr, deterministic, stream,
+                             "bpp_masked_act: NULL pointer / non-positive size");
+}
+
+int bpp_masked_act_counter(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                           int64_t env_id_base, const uint64_t *seed_step, int32_t deterministic, void *stream) {
+    if (!seed_step) return fail(BPP_E_BADARG, "bpp_masked_act_counter: NULL seed_step");
+    return masked_act_launch(logits, mask, action, log_prob, E, M, env_id_base, 0, 0, seed_step, deterministic, stream,
+                             "bpp_masked_act_counter: NULL pointer / non-positive size");
 }
 
 int bpp_masked_evaluate(const float *logits, const float *mask, const int64_t *action, float *log_prob, float *entropy,

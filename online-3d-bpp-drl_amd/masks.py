@@ -142,23 +142,38 @@ def get_rotation_mask(observation, container_size):
     return _row_mask(observation, container_size, True)
 
 
-def masked_act(logits, location_masks, seed=0, step=0, deterministic=False, env_id_base=0):
+def masked_act(logits, location_masks, seed=0, step=0, deterministic=False, env_id_base=0, counter=None, out=None):
     """Fused replacement of the inference half of `Categorical.forward` + `dist.sample()/mode()` +
     `dist.log_probs(action)` in `Policy.act` (acktr/model.py:56-68, acktr/distributions.py:71-84):
     logits [E,M] (output of the policy's linear layer) and location_masks [E,M] float32 device tensors ->
     (action int64 [E,1], action_log_probs float32 [E,1]).  Sampling uses a counter-based stream keyed by
-    (seed, global bin id, step) instead of torch.multinomial."""
+    (seed, global bin id, step) instead of torch.multinomial.
+    counter: int64 / uint64 device tensor [2] = (seed, step) read BY THE KERNEL (bpp_masked_act_counter) -- for loops captured
+    in a HIP graph, where `step` passed by value would be frozen into the captured launch: advance `counter[1]` on the
+    device (`counter[1:].add_(1)`) inside the captured region.  out = (action, log_prob) tensors to write into (static outputs for a captured region)."""
     dev = logits.device if logits.device.type == "cuda" else _dev()
     x = logits.to(device=dev, dtype=torch.float32).contiguous()
     m = location_masks.to(device=dev, dtype=torch.float32).contiguous()
     if x.shape != m.shape or x.dim() != 2:
         raise ValueError("logits and location_masks must both be [E, M]")
     E, M = x.shape
-    action = torch.empty((E, 1), dtype=torch.int64, device=dev)
-    logp = torch.empty((E, 1), dtype=torch.float32, device=dev)
+    if out is not None:
+        action, logp = out
+        if (action.dtype != torch.int64 or logp.dtype != torch.float32 or action.numel() != E or logp.numel() != E
+                or action.device != dev or logp.device != dev or not action.is_contiguous() or not logp.is_contiguous()):
+            raise ValueError("out must be (int64 [E,1], float32 [E,1]) contiguous tensors on the logits' device")
+    else:
+        action = torch.empty((E, 1), dtype=torch.int64, device=dev)
+        logp = torch.empty((E, 1), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().bpp_masked_act(x.data_ptr(), m.data_ptr(), action.data_ptr(), logp.data_ptr(), E, M,
-                                             int(env_id_base), int(seed), int(step), int(bool(deterministic)), _stream(dev)))
+        if counter is not None:
+            if counter.device != dev or counter.numel() != 2 or counter.dtype not in (torch.int64, torch.uint64) or not counter.is_contiguous():
+                raise ValueError("counter must be a contiguous int64 / uint64 [2] tensor (seed, step) on the logits' device")
+            _lib.check(_lib.lib().bpp_masked_act_counter(x.data_ptr(), m.data_ptr(), action.data_ptr(), logp.data_ptr(), E, M,
+                                                         int(env_id_base), counter.data_ptr(), int(bool(deterministic)), _stream(dev)))
+        else:
+            _lib.check(_lib.lib().bpp_masked_act(x.data_ptr(), m.data_ptr(), action.data_ptr(), logp.data_ptr(), E, M,
+                                                 int(env_id_base), int(seed), int(step), int(bool(deterministic)), _stream(dev)))
     return action, logp
 
 

@@ -629,6 +629,12 @@ int bpp_masked_act(const float *logits, const float *mask, int64_t *action, floa
     return 0;
 }
 
+int bpp_masked_act_counter(const float *logits, const float *mask, int64_t *action, float *log_prob, int32_t E, int32_t M,
+                           int64_t env_id_base, const uint64_t *seed_step, int32_t deterministic, void *stream) {
+    if (!seed_step) return fail(BPP_E_BADARG, "bpp_masked_act_counter: NULL seed_step");     /* include/bpp_abi.h: (seed, step) from memory */
+    return bpp_masked_act(logits, mask, action, log_prob, E, M, env_id_base, seed_step[0], seed_step[1], deterministic, stream);
+}
+
 /* Training half: acktr/distributions.py:71-101 as consumed by Policy.evaluate_actions (acktr/model.py:90-96):
  * Categorical(probs = softmax(x - 14 (1 - m)) + 1e-5): log_prob of the taken action, entropy, and the row sum of
  * bx = softmax(x) * (1 - m).  float32, sequential sums. */

@@ -99,6 +99,8 @@ def lib():
                                            ctypes.c_uint32, ctypes.c_void_p]
         L.bpp_masked_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p]
+        L.bpp_masked_act_counter.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_evaluate.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_masked_evaluate_backward.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         L.bpp_gen_cut2.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_uint64, ctypes.c_int32]
@@ -339,11 +341,17 @@ def masked_evaluate_backward(logits, mask, action, g_lp, g_ent, g_bad):
     return grad
 
 
-def masked_act(logits, mask, seed, step, deterministic=False, env_id_base=0):
+def masked_act(logits, mask, seed, step, deterministic=False, env_id_base=0, counter=False):
+    """counter=True: through bpp_masked_act_counter, (seed, step) handed over in memory"""
     logits = np.ascontiguousarray(logits, dtype=np.float32)
     mask = np.ascontiguousarray(mask, dtype=np.float32)
     a = np.zeros(logits.shape[0], np.int64)
     lp = np.zeros(logits.shape[0], np.float32)
+    if counter:
+        ss = np.array([int(seed), int(step)], np.uint64)
+        _check(lib().bpp_masked_act_counter(_p(logits), _p(mask), _p(a), _p(lp), logits.shape[0], logits.shape[1], int(env_id_base), _p(ss),
+                                            int(bool(deterministic)), None))
+        return a, lp
     _check(lib().bpp_masked_act(_p(logits), _p(mask), _p(a), _p(lp), logits.shape[0], logits.shape[1], int(env_id_base),
                                 int(seed), int(step), int(bool(deterministic)), None))
     return a, lp

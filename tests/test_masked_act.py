@@ -137,3 +137,78 @@ def test_oracle_masked_act_against_the_reference_policy_head(oracle):
             a1, lp1 = oracle.masked_act(logits, mask, 5, 1, False)
             np.testing.assert_allclose(lp1, d2.log_prob(torch.from_numpy(a1)).numpy(), atol=5e-6)
             assert (mask[np.arange(E), a1] == 1).mean() > 0.95          # draws land on feasible positions
+
+
+def test_oracle_masked_act_counter_equals_by_value(oracle):
+    """bpp_masked_act_counter (ABI v16): (seed, step) handed over in memory give the draws of the by-value entry point."""
+    x, m = make_case(200, 100, 3)
+    for det in (False, True):
+        a0, l0 = oracle.masked_act(x, m, 11, 42, det)
+        a1, l1 = oracle.masked_act(x, m, 11, 42, det, counter=True)
+        np.testing.assert_array_equal(a0, a1)
+        np.testing.assert_array_equal(l0, l1)
+    assert (oracle.masked_act(x, m, 11, 43, False, counter=True)[0] != a0).any()
+
+
+def test_emulated_masked_act_counter_equals_by_value(emu):
+    x, m = make_case(70, 100, 4)
+    for M in (100, 7):
+        for det in (False, True):
+            a0, l0 = emu.masked_act(x[:, :M], m[:, :M], 5, 9, det)
+            a1, l1 = emu.masked_act(x[:, :M], m[:, :M], 5, 9, det, counter=True)
+            np.testing.assert_array_equal(a0, a1)
+            np.testing.assert_array_equal(l0, l1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E,rot", [(64, False), (1024, True)])
+def test_gpu_lock_step_captured_in_a_hip_graph_equals_the_eager_loop(E, rot):
+    """A whole lock-step -- a policy forward, bpp_masked_act_counter (its (seed, step) in device memory), the fused environment
+    step, the counter's increment -- captured ONCE in a HIP graph and replayed 40 times leaves exactly the heightmaps, per-bin
+    records, observations, masks and episode accumulators the eager loop leaves (the by-value bpp_masked_act with step = t)."""
+    import torch
+    import bpp_amd
+    size = (10, 10, 10)
+    pool = bpp_amd.sequences.cut2_pool(size, 256, seed=0)
+    torch.manual_seed(0)
+    M = 100 * (1 + rot)
+    Wt = (torch.randn(400, M, device="cuda") * 0.05)
+
+    def build():
+        env = bpp_amd.BppVecEnv(E, size, enable_rotation=rot, pool=pool)
+        return env, env.reset(), env.location_masks
+
+    steps = 40
+    env_a, obs_a, mask_a = build()
+    for t in range(steps):
+        action, _ = bpp_amd.masked_act(obs_a @ Wt, mask_a, seed=7, step=t)
+        env_a.step_tensors(action)
+
+    env_b, obs_b, mask_b = build()
+    counter = torch.tensor([7, 0], dtype=torch.int64, device="cuda")
+    out = (torch.empty((E, 1), dtype=torch.int64, device="cuda"), torch.empty((E, 1), dtype=torch.float32, device="cuda"))
+
+    def one_step():
+        bpp_amd.masked_act(obs_b @ Wt, mask_b, counter=counter, out=out)
+        env_b.step_tensors(out[0])
+        counter[1:].add_(1)
+
+    warm = 3
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            one_step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one_step()
+    for _ in range(steps - warm - 1):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(counter[1].item()) == steps
+    for name in ("hmap", "state", "ep_acc"):
+        assert torch.equal(getattr(env_a, name), getattr(env_b, name)), name
+    assert torch.equal(obs_a, obs_b) and torch.equal(mask_a, mask_b)
+    assert float(env_b.ep_acc[:, 3].sum().item()) > 0           # episodes finished inside the replays
