@@ -164,7 +164,7 @@ def test_emulated_masked_act_counter_equals_by_value(emu):
 @pytest.mark.parametrize("E,rot", [(64, False), (1024, True)])
 def test_gpu_lock_step_captured_in_a_hip_graph_equals_the_eager_loop(E, rot):
     """A whole lock-step -- a policy forward, bpp_masked_act_counter (its (seed, step) in device memory), the fused environment
-    step, the counter's increment -- captured ONCE in a HIP graph and replayed 40 times leaves exactly the heightmaps, per-bin
+    step, the counter's increment -- captured ONCE in a HIP graph and replayed 37 times (after 3 eager lock-steps) leaves exactly the heightmaps, per-bin
     records, observations, masks and episode accumulators the eager loop leaves (the by-value bpp_masked_act with step = t)."""
     import torch
     import bpp_amd
@@ -204,7 +204,7 @@ def test_gpu_lock_step_captured_in_a_hip_graph_equals_the_eager_loop(E, rot):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         one_step()
-    for _ in range(steps - warm - 1):
+    for _ in range(steps - warm):          # (the capture itself executes nothing)
         g.replay()
     torch.cuda.synchronize()
     assert int(counter[1].item()) == steps
