@@ -740,7 +740,11 @@ def main():
     bpp_amd, world, rank = ctx.bpp, ctx.world, ctx.rank
     size = tuple(args.size)
     E = args.envs
-    ctx.early_device()
+    # (rank 0 of a launcher-started job forks the CPU baseline's workers further down: it touches its GPU -- device 0, the
+    # default anyway -- only after that; every other rank makes its device current before the library is loaded)
+    will_fork = ctx.rank == 0 and ctx.world > 1 and not args.no_cpu_baseline and not os.environ.get("BPP_BENCH_CPU_BASELINE_FILE")
+    if not will_fork:
+        ctx.early_device()
     stream = dict(bound=(2, 5), seed=0, depth=args.stream_depth, refill_every=args.stream_refill, rng=args.stream_rng,
                   cache={"auto": None, "on": True, "off": False}[args.stream_cache]) if args.stream else None
     if args.pool_file:
@@ -793,6 +797,7 @@ def main():
                             "sample": "cpu baseline failed: %r" % (exc,)}
             if world > 1:
                 cpu_base["timed_by"] = "rank 0 before any rank touched its GPU (the other %d ranks waited in the rendezvous)" % (world - 1)
+                ctx.early_device()
     ctx.init_device()
     res = run_workload(ctx, main_spec)
     extras = [run_workload(ctx, sp) for sp in extra_specs]
