@@ -37,6 +37,13 @@ cp profiles/hbm_traffic.json $O/hbm_traffic.json; cp profiles/${TAG}_pmc_summary
 python tools/bench_mask_kernels.py > $O/mask_and_reset_kernels.json 2>> $O/bench.err
 python tools/bench_dropin_step.py > $O/dropin_step.json 2>> $O/bench.err
 python tools/bench_acc_reduce.py > $O/acc_reduce.json 2>> $O/bench.err
+python tools/bench_dropin_scale.py > $O/dropin_scale.json 2>> $O/bench.err                                 # the drop-in at the reference's own scale
+python tools/bench_dropin_scale.py --rotation --envs 16,1024 > $O/dropin_scale_rot.json 2>> $O/bench.err
+python tools/bench_masked_act.py > $O/masked_act.json 2>> $O/bench.err
+for ck in default_cut_2:"" rotation_cut_2:--rotation; do                                                   # the reference's checkpoints on its whole test set, one batch
+  python examples/evaluate_checkpoint.py --checkpoint oracle/_ref/pretrained_models/${ck%%:*}.pt --dataset oracle/_ref/dataset/cut_2.pt ${ck#*:} >> $O/evaluate_checkpoint.txt 2>> $O/bench.err
+done
+for e in 16 64 1024; do for g in "" "--graph"; do python examples/rollout_with_policy.py --envs $e --steps 1000 $g 2>> $O/bench.err | tail -1 >> $O/rollout_with_policy_graph.txt; done; done
 for cfg in "mt19937_d32_r14:" "mt19937_d64_r30:--stream-depth 64 --stream-refill 30" "counter_d32_r14:--stream-rng counter" \
            "counter_d64_r30:--stream-rng counter --stream-depth 64 --stream-refill 30" \
            "counter_rot_d64_r30:--stream-rng counter --rotation --stream-depth 64 --stream-refill 30" \
