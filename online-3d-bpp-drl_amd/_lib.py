@@ -15,7 +15,7 @@ SRC = os.path.join(CSRC, "bpp_kernels.hip")
 BUILD_LIB = os.path.join(CSRC, "libbpp_hip.so")
 LIB = os.environ.get("BPP_HIP_LIB") or BUILD_LIB
 HDR = os.path.join(os.path.dirname(HERE), "include", "bpp_abi.h")
-DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_tile_body.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
+DEPS = [SRC, HDR, os.path.join(CSRC, "bpp_tile_kernel.inl"), os.path.join(CSRC, "bpp_tile_body.inl"), os.path.join(CSRC, "bpp_stream_gen.inl"), os.path.join(CSRC, "bpp_heads.inl"), os.path.join(CSRC, "bpp_rt_kernels.inl"), os.path.join(CSRC, "bpp_stats.inl"), os.path.join(os.path.dirname(HERE), "include", "bpp_gen.inl")]
 
 ABI_VERSION = 16
 STREAM_RNG_MT19937, STREAM_RNG_COUNTER = 0, 1

@@ -362,1720 +362,13 @@ __device__ __forceinline__ uint32_t mix32(uint32_t base, uint32_t gid) {
     return h;
 }
 
-template <bool VEC, int MODE>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void bpp_kernel(const Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wid = threadIdx.x >> 6;
-    const int e0 = (xcd_block(p.xcd_remap) * (blockDim.x >> 6) + wid) * p.epw;
-    if (e0 >= p.E) return;  // no block-level barrier is ever used, a whole wave may leave
-    const int nenv = min(p.epw, p.E - e0);
-    const int A = p.A, L = p.L, M = p.M;
-    unsigned char *wb = smem + wid * p.lds_per_wave;
-    uint8_t *hm = wb;                        // [epw][A] heights
-    uint8_t *mk = wb + p.off_mk;             // [epw][M] feasibility bytes
-    BinRec *rec = (BinRec *)(wb + p.off_rec);  // [epw]
-    const int ncell = nenv * A;
-    constexpr int GW = VEC ? 4 : 1;          // cells handled per lane per access
-
-    // ---- phase 1: stage this wave's heightmaps into LDS as bytes -------------------------------
-    if (MODE == kStep) {
-        const uint8_t *gh = p.hmap + (size_t)e0 * A;
-        if (VEC) {
-            for (int q = lane; q < ncell / 4; q += kWave) ((uint32_t *)hm)[q] = ((const uint32_t *)gh)[q];
-        } else {
-            for (int c = lane; c < ncell; c += kWave) hm[c] = gh[c];
-        }
-    } else if (MODE == kMaskHmap) {
-        const int32_t *gh = p.hmap_in + (size_t)e0 * A;
-        if (VEC) {
-            for (int q = lane; q < ncell / 4; q += kWave) {
-                int4 v = ((const int4 *)gh)[q];
-                ((uint32_t *)hm)[q] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) | (min((uint32_t)v.z, 255u) << 16) |
-                                      (min((uint32_t)v.w, 255u) << 24);
-            }
-        } else {
-            for (int c = lane; c < ncell; c += kWave) hm[c] = (uint8_t)min((uint32_t)gh[c], 255u);
-        }
-    } else if (MODE == kMaskObs) {
-        // acktr/utils.py:41-47: plane 0 of the observation row is the heightmap
-        if (VEC) {
-            for (int q = lane; q < ncell / 4; q += kWave) {
-                uint32_t el = p.divA4.div(q);  // bin within the wave (A/4 quads per bin)
-                float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * (A / 4)];
-                ((uint32_t *)hm)[q] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
-                                      (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
-            }
-        } else {
-            for (int c = lane; c < ncell; c += kWave) {
-                uint32_t el = p.divA.div(c);
-                hm[c] = (uint8_t)min((uint32_t)(int)p.obs_in[(size_t)(e0 + el) * 4 * A + (c - el * A)], 255u);
-            }
-        }
-    } else {
-        if (VEC) {
-            for (int q = lane; q < ncell / 4; q += kWave) ((uint32_t *)hm)[q] = 0u;  // space.py:22
-        } else {
-            for (int c = lane; c < ncell; c += kWave) hm[c] = 0;
-        }
-    }
-    wave_sync();
-
-    // ---- phase 2: lane-per-bin scalar work ------------------------------------------------------
-    bool fin = false;
-    double fin_ret = 0.0, fin_ratio = 0.0;
-    int fin_len = 0;
-    if (lane < nenv) {
-        const int e = e0 + lane;
-        BinRec r;
-        r.place = 0;
-        r.flags = 0;
-        r.any = 0;
-        if (MODE == kStep) {
-            bpp_env_state st = p.state[e];
-            const int64_t act = p.actions[e];
-            // BoxCreator.preview(1)[0] (binCreator.py:15-18): the current item, the one after it and the
-            // first item of the next episode are cached in the state record; the entries the NEXT step
-            // will need are fetched here, speculatively for both outcomes, off the critical path.
-            const int T = p.T;
-            int seq_n = st.seq + p.seq_stride;
-            seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
-            int seq_nn = seq_n + p.seq_stride;
-            seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
-            const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-            const LookAheadAt la = look_ahead_at(p, st.seq, seq_n, seq_nn, st.cursor);
-            const uint32_t sp_ok = p.pool[la.ok], sp_f1 = p.pool[la.f1], sp_f2 = p.pool[la.f2];
-            const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
-            // bin3D.py:96-105: rotated iff idx > area (strict)
-            const bool noop = act == BPP_ACTION_NOOP;   // include/bpp_abi.h: the bin is left alone
-            int64_t idx = act;
-            const bool flag = p.rotation && idx > A;
-            if (flag) idx -= A;
-            const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
-            bool ok = idx >= 0 && idx < (int64_t)(p.W + 1) * L;
-            int lx = 0, ly = 0, top = 0;
-            if (ok) {
-                lx = (int)p.divL.div((uint32_t)idx);  // space.py:153-156
-                ly = (int)idx - lx * L;
-                ok = (lx + x <= p.W) && (ly + y <= L);  // space.py:112-115
-            }
-            if (ok) {
-                Win w = scan_window(hm + lane * A, L, lx, ly, x, y);
-                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);  // space.py:117-144
-                top = w.mh + z;                                   // space.py:42-45 with lz = max_h
-            }
-            const int vol = ix * iy * iz;
-            // bin3D.py:44-46,108-121: float64 (vol / binvol) * 10, 0.0 on failure
-            const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;
-            st.n_boxes += ok ? 1 : 0;
-            st.vol_sum += ok ? vol : 0;
-            st.ep_ret = st.ep_ret + rew;  // bench/monitor.py:58-62 (sum in step order)
-            st.ep_len += noop ? 0 : 1;
-            p.reward[e] = (float)rew;     // acktr/envs.py:192
-            p.done[e] = (ok || noop) ? 0 : 1;
-            if (p.host_reward) {
-                p.host_reward[e] = (float)rew;
-                p.host_done[e] = (ok || noop) ? 0 : 1;
-            }
-            p.counter[e] = st.n_boxes;    // bin3D.py:111,124
-            p.ratio[e] = (double)st.vol_sum / p.binvol;  // space.py:146-151
-            p.ep_ret[e] = st.ep_ret;
-            p.ep_len[e] = st.ep_len;
-            fin = !ok && !noop;
-            fin_ret = st.ep_ret;
-            fin_ratio = (double)st.vol_sum / p.binvol;
-            fin_len = st.ep_len;
-            if (ok) {
-                st.cursor += 1;  // bin3D.py:116-117
-                st.item_cur = it_nxt;
-                st.item_next = sp_ok;
-                st.hmax = max(st.hmax, (uint32_t)top);   // highest cell of the bin
-                r.item = it_nxt;
-                r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
-                r.flags = 1u | ((uint32_t)top << 8);
-            } else if (noop) {
-                r.item = it_cur;
-            } else {  // shmem_vec_env.py:128-129 auto-reset; bin3D.py:55-59
-                st.episode += 1;
-                st.seq = seq_n;
-                st.cursor = 0;
-                st.n_boxes = 0;
-                st.vol_sum = 0;
-                st.ep_ret = 0.0;
-                st.ep_len = 0;
-                st.item_cur = it_rst;
-                st.item_next = sp_f1;
-                st.item_reset = sp_f2;
-                st.hmax = 0;
-                r.item = it_rst;
-                r.flags = 2u;
-            }
-            p.state[e] = st;
-            if (p.cache != nullptr) row_cache_drop(p, e);
-        } else if (MODE == kResetInit || MODE == kResetAdvance) {
-            bpp_env_state st;
-            if (MODE == kResetInit) {
-                st.episode = 0;
-                st.seq = (int32_t)(((uint32_t)p.base_mod + (uint32_t)e) % (uint32_t)p.P);
-            } else {
-                st = p.state[e];
-                st.episode += 1;
-                int s = st.seq + p.seq_stride;
-                st.seq = s >= p.P ? s - p.P : s;
-            }
-            st.cursor = 0;
-            st.n_boxes = 0;
-            st.vol_sum = 0;
-            st.ep_ret = 0.0;
-            st.ep_len = 0;
-            int sn = st.seq + p.seq_stride;
-            sn = sn >= p.P ? sn - p.P : sn;
-            st.item_cur = p.pool[(size_t)st.seq * p.T + p.ring2];
-            st.item_next = p.pool[(size_t)st.seq * p.T + p.ring2 + min(1, p.T - 1 - p.ring2)];
-            st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
-            st.hmax = 0;
-            p.state[e] = st;
-            if (p.cache != nullptr) row_cache_drop(p, e);
-            r.item = st.item_cur;
-            r.flags = 2u;
-        } else if (MODE == kMaskObs) {
-            // acktr/utils.py:43-45: x, y, z = int(plane[k][0])
-            const float *o = p.obs_in + (size_t)e * 4 * A;
-            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
-        } else {
-            const int32_t *it = p.items_in + (size_t)e * 3;
-            r.item = pack_item(it[0], it[1], it[2]);
-        }
-        rec[lane] = r;
-    }
-    if (MODE == kStep && p.ep_acc && fin) episode_acc_add(p.ep_acc, e0 + lane, fin_ret, fin_ratio, fin_len);
-    wave_sync();
-
-    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
-        // ---- phase 3a: apply the placement / reset to the LDS tile (space.py:36-46) -------------
-        if (MODE == kStep) {
-            for (int g = lane; g < ncell / GW; g += kWave) {
-                uint32_t packed = VEC ? ((uint32_t *)hm)[g] : (uint32_t)hm[g];
-                uint32_t outv = 0;
-#pragma unroll
-                for (int k = 0; k < GW; ++k) {
-                    const uint32_t c = g * GW + k;
-                    const uint32_t el = p.divA.div(c);
-                    const uint32_t cell = c - el * A;
-                    const uint32_t i = p.divL.div(cell), j = cell - i * L;
-                    const BinRec r = rec[el];
-                    uint32_t v = (packed >> (8 * k)) & 255u;
-                    const uint32_t lx = r.place & 255u, ly = (r.place >> 8) & 255u;
-                    const uint32_t x = (r.place >> 16) & 255u, y = r.place >> 24;
-                    if ((r.flags & 1u) && (i - lx) < x && (j - ly) < y) v = r.flags >> 8;
-                    if (r.flags & 2u) v = 0;
-                    outv |= v << (8 * k);
-                }
-                if (VEC) ((uint32_t *)hm)[g] = outv;
-                else hm[g] = (uint8_t)outv;
-            }
-            wave_sync();
-        }
-        // ---- phase 3b: stream out the byte heightmap (state) and the float32 observation -----------
-        // bin3D.py:49-66: planes [hmap, x, y, z]; float32 at the VecEnv buffer (shmem_vec_env.py:42-43)
-        {
-            uint8_t *gh = p.hmap + (size_t)e0 * A;
-            float *go = p.obs + (size_t)e0 * 4 * A;
-            const int per_plane = A / GW;
-            for (int g = lane; g < nenv * 4 * per_plane; g += kWave) {
-                const uint32_t pl = p.divA4.div(g);  // plane counter: bin*4 + plane
-                const uint32_t k = g - pl * per_plane;
-                const uint32_t el = pl >> 2, plane = pl & 3u;
-                if (plane == 0) {
-                    if (VEC) {
-                        const uint32_t v = ((uint32_t *)hm)[el * per_plane + k];
-                        ((uint32_t *)gh)[el * per_plane + k] = v;
-                        ((float4 *)go)[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                        (float)(v >> 24));
-                    } else {
-                        const int v = hm[el * A + k];
-                        gh[el * A + k] = (uint8_t)v;
-                        go[g] = (float)v;
-                    }
-                } else {
-                    const float f = (float)((rec[el].item >> (8 * (plane - 1))) & 255u);
-                    if (VEC) ((float4 *)go)[g] = make_float4(f, f, f, f);
-                    else go[g] = f;
-                }
-            }
-        }
-        if (p.mask == nullptr) return;
-    }
-
-    // ---- phase 4: feasibility of every candidate position (acktr/utils.py:37-94) ---------------
-    for (int c = lane; c < nenv * M; c += kWave) {
-        const uint32_t el = p.divM.div(c);
-        uint32_t r = c - el * M;
-        const bool rot = r >= (uint32_t)A;  // second half: item turned by 90 degrees, utils.py:81-89
-        if (rot) r -= A;
-        const uint32_t i = p.divL.div(r), j = r - i * L;
-        const uint32_t item = rec[el].item;
-        const int ix = item & 255u, iy = (item >> 8) & 255u, z = (item >> 16) & 255u;
-        const int x = rot ? iy : ix, y = rot ? ix : iy;
-        bool f = false;
-        if (x >= 1 && y >= 1 && (int)i + x <= p.W && (int)j + y <= L) {  // utils.py:54-55 loop ranges (a zero-sized side never fits, like the fast path)
-            Win w = scan_window(hm + el * A, L, i, j, x, y);
-            f = feasible(w, x * y, z, p.H, p.rule);
-        }
-        mk[c] = f ? 1 : 0;
-        if (f) rec[el].any = 1u;
-    }
-    wave_sync();
-
-    // ---- phase 5: float32 mask out, all-ones when nothing is feasible (utils.py:59-60,91-92) ---
-    {
-        float *gm = p.mask + (size_t)e0 * M;
-        if (VEC) {
-            const int per = M / 4;
-            for (int g = lane; g < nenv * per; g += kWave) {
-                const uint32_t el = p.divA4.div(p.rotation ? (g >> 1) : g);  // g / (M/4)
-                const uint32_t v = rec[el].any ? ((uint32_t *)mk)[g] : 0x01010101u;
-                ((float4 *)gm)[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                (float)(v >> 24));
-            }
-        } else {
-            for (int c = lane; c < nenv * M; c += kWave) {
-                const uint32_t el = p.divM.div(c);
-                gm[c] = rec[el].any ? (float)mk[c] : 1.0f;
-            }
-        }
-    }
-}
-
-
-// =================================================================================================
-// Fast path: compile-time geometry + packed-histogram integral image
-// =================================================================================================
-// The generic kernel above walks every candidate's x*y window cell by cell (14 instructions and one
-// LDS round trip per cell).  Here every cell of height h is coded as the 64-bit integer 1 << (5*h)
-// -- a histogram over height levels with 5-bit counters -- and a 2-D inclusive prefix sum P of the
-// codes is built in LDS once per step (two scans).  The histogram of ANY window of <= 31 cells is then
-//   P[i+x][j+y] - P[i][j+y] - P[i+x][j] + P[i][j]          (plain 64-bit integer arithmetic; prefix
-// totals may overflow a field, the final difference cannot), its top set field is max_h and that
-// field's value is max_area: 4 LDS reads + 3 subtractions + one clz per candidate, no loop.
-// 12 levels fit one word (H <= 10 leaves level H+1 for out-of-range inputs), K words cover
-// H + 2 <= 12*K.  Windows of more than 31 cells (the bin-sized terminator item) are tiled into
-// <= 5x6 pieces whose (max, count) pairs are merged.
-constexpr int kFieldBits = 5;
-constexpr int kLevelsPerWord = 12;
-constexpr int kTileX = 5, kTileY = 6;
-
-template <int K>
-struct __attribute__((aligned(8 * K))) Ent {
-    uint64_t w[K];
-};
-
-template <int K>
-__device__ __forceinline__ Ent<K> code_of(uint32_t h) {
-    Ent<K> c;
-    if (K == 1) {
-        c.w[0] = 1ull << (kFieldBits * h);
-    } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t rel = h - kLevelsPerWord * k;  // wraps to a huge value when h is below this word
-            c.w[k] = rel < (uint32_t)kLevelsPerWord ? 1ull << (kFieldBits * rel) : 0ull;
-        }
-    }
-    return c;
-}
-
-// One-word codes of a bin whose heights need two words, one word at a time (bpp_tile_kernel's two-phase scan of tall
-// 20x20 bins): PH = 1 -> the upper word (levels 12..23, zero for lower cells), PH = 2 -> the lower word (levels 0..11,
-// zero for higher cells); PH = 0 -> the plain one-word code (every height <= 11).
-template <int PH>
-__device__ __forceinline__ Ent<1> code_phase(uint32_t h) {
-    Ent<1> c;
-    if (PH == 0) {
-        c.w[0] = 1ull << (kFieldBits * h);
-    } else {
-        const uint32_t rel = PH == 1 ? h - (uint32_t)kLevelsPerWord : h;   // wraps to a huge value below the upper word
-        c.w[0] = rel < (uint32_t)kLevelsPerWord ? 1ull << (kFieldBits * rel) : 0ull;
-    }
-    return c;
-}
-
-// Highest non-empty level of a window histogram and the count stored there.
-template <int K>
-__device__ __forceinline__ void top_of(const Ent<K> &h, int &m, int &cnt) {
-    uint64_t v = h.w[0];
-    int word = 0;
-#pragma unroll
-    for (int k = 1; k < K; ++k)
-        if (h.w[k] != 0) {
-            v = h.w[k];
-            word = k;
-        }
-    const int msb = 63 - __builtin_clzll(v);
-    const int lvl = (msb * 13) >> 6;  // msb / 5 for msb <= 63
-    cnt = (int)(v >> (kFieldBits * lvl));  // lvl is the top non-empty field: nothing above it to mask off
-    m = word * kLevelsPerWord + lvl;
-}
-
-template <int K, bool ZERO_OK = false>
-__device__ __forceinline__ void rect_top(const Ent<K> *P00, int PW, int xa, int yb, int &m, int &cnt) {
-    const Ent<K> a = P00[0], b = P00[yb], c = P00[xa * PW], d = P00[xa * PW + yb];
-    Ent<K> h;
-#pragma unroll
-    for (int k = 0; k < K; ++k) h.w[k] = d.w[k] - b.w[k] - c.w[k] + a.w[k];
-    top_of<K>(h, m, cnt);
-    if (ZERO_OK && K == 1 && h.w[0] == 0ull) {   // no cell of this rectangle has a level in the word scanned: contributes nothing
-        m = -1;
-        cnt = 0;
-    }
-}
-
-// (max_h, max_area) of window [i,i+x) x [j,j+y) from the bin's prefix image (acktr/utils.py:14-16).
-template <int K, bool ZERO_OK = false>
-__device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int j, int x, int y, int &mh, int &ma) {
-    if (x <= kTileX && y <= kTileY) {
-        rect_top<K, ZERO_OK>(Pb + i * PW + j, PW, x, y, mh, ma);
-        return;
-    }
-    mh = -1;
-    ma = 0;
-    // (rare path -- items wider than 5 x 6, in the benchmark only the bin-sized terminator: kept rolled, an unrolled
-    // copy of these loops was what set the kernels' scalar-register count and cost the 10x10 + rotation kernel a workgroup slot per CU)
-#pragma unroll 1
-    for (int a0 = 0; a0 < x; a0 += kTileX) {
-        const int xa = min(kTileX, x - a0);
-#pragma unroll 1
-        for (int b0 = 0; b0 < y; b0 += kTileY) {
-            const int yb = min(kTileY, y - b0);
-            int m, c;
-            rect_top<K, ZERO_OK>(Pb + (i + a0) * PW + (j + b0), PW, xa, yb, m, c);
-            ma = m > mh ? c : ma + (m == mh ? c : 0);
-            mh = max(mh, m);
-        }
-    }
-}
-
-// Prefix image of ONE bin by a whole wave (used when a wave owns a single bin, e.g. the 20x20 bin
-// whose image is 7 KB): every row is split into SEG = 64/W segments so that W*SEG (60 of 64 for W = 20)
-// lanes scan concurrently; each lane scans its <= CS cells, the segment totals are exchanged with
-// __shfl_up and added as offsets.  Same for the column pass.  (With lane-per-row scans only W of 64 lanes
-// worked and this phase was 27 % of the 20^3 step.)
-template <int K>
-__device__ __forceinline__ Ent<K> shfl_up_ent(const Ent<K> &v, int d) {
-    Ent<K> r;
-#pragma unroll
-    for (int k = 0; k < K; ++k) r.w[k] = (uint64_t)__shfl_up((unsigned long long)v.w[k], d, kWave);
-    return r;
-}
-
-template <int W, int L, int K, int PH = 0>
-__device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *P, uint32_t hclamp, int lane) {
-    constexpr int PW = L + 1;
-    constexpr int SR = (kWave / W) < 1 ? 1 : (kWave / W), CSR = (L + SR - 1) / SR;  // row pass: segments along j
-    constexpr int SC = (kWave / L) < 1 ? 1 : (kWave / L), CSC = (W + SC - 1) / SC;  // column pass: segments along i
-    Ent<K> zero;
-#pragma unroll
-    for (int k = 0; k < K; ++k) zero.w[k] = 0;
-    for (int t = lane; t < PW + W; t += kWave) P[t < PW ? t : (t - PW + 1) * PW] = zero;  // row 0, column 0
-    {
-        const int i = lane / SR, sg = lane - i * SR;
-        const bool act = i < W;
-        const int j0 = sg * CSR;
-        const uint8_t *row = hm + (act ? i : 0) * L;
-        Ent<K> s[CSR];
-        Ent<K> run = zero;
-#pragma unroll
-        for (int c = 0; c < CSR; ++c) {
-            const int j = j0 + c;
-            if (j < L) {
-                Ent<K> cd;
-                if constexpr (K == 1 && PH != 0) cd = code_phase<PH>(min((uint32_t)row[j], hclamp));
-                else cd = code_of<K>(min((uint32_t)row[j], hclamp));
-#pragma unroll
-                for (int k = 0; k < K; ++k) run.w[k] += cd.w[k];
-            }
-            s[c] = run;
-        }
-        Ent<K> off = zero;
-#pragma unroll
-        for (int d = 1; d < SR; ++d) {
-            const Ent<K> t = shfl_up_ent<K>(run, d);
-            if (sg >= d) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) off.w[k] += t.w[k];
-            }
-        }
-        if (act) {
-            Ent<K> *pr = P + (i + 1) * PW + 1;
-#pragma unroll
-            for (int c = 0; c < CSR; ++c)
-                if (j0 + c < L) {
-                    Ent<K> o;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) o.w[k] = s[c].w[k] + off.w[k];
-                    pr[j0 + c] = o;
-                }
-        }
-    }
-    wave_sync();
-    {
-        const int j = lane / SC, sg = lane - j * SC;
-        const bool act = j < L;
-        const int i0 = sg * CSC;
-        Ent<K> *pc = P + PW + ((act ? j : 0) + 1);
-        Ent<K> s[CSC];
-        Ent<K> run = zero;
-#pragma unroll
-        for (int c = 0; c < CSC; ++c) {
-            const int i = i0 + c;
-            if (i < W) {
-                const Ent<K> v = pc[i * PW];
-#pragma unroll
-                for (int k = 0; k < K; ++k) run.w[k] += v.w[k];
-            }
-            s[c] = run;
-        }
-        Ent<K> off = zero;
-#pragma unroll
-        for (int d = 1; d < SC; ++d) {
-            const Ent<K> t = shfl_up_ent<K>(run, d);
-            if (sg >= d) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) off.w[k] += t.w[k];
-            }
-        }
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < CSC; ++c)
-                if (i0 + c < W) {
-                    Ent<K> o;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) o.w[k] = s[c].w[k] + off.w[k];
-                    pc[(i0 + c) * PW] = o;
-                }
-        }
-    }
-    wave_sync();
-}
-
-// Per-bin, per-orientation constants of the item shown in the next observation, computed once by the
-// bin's lane and read (one ds_read_b128) by every candidate lane.  The float64 ratio tests of
-// acktr/utils.py:28-33 become integer thresholds on max_area:
-//   ma/area > 0.95  <=>  ma >= floor(19*area/20) + 1   (t95), likewise t85 (17/20) and t50 (1/2).
-constexpr int kCandShift = 22;  // candidate index decode, see make_ori
-struct __attribute__((aligned(16))) OriRec {
-    uint32_t a;  // x | y<<8 | (max(H - z + 1, 0))<<16 (9 bits) | big<<25 | valid<<26
-    uint32_t b;  // t95 | t85<<16
-    uint32_t c;  // t50 | (W - x)<<16 | (L - y)<<24
-    uint32_t d;
-};
-
-__device__ __forceinline__ OriRec make_ori(int W, int L, int x, int y, int z, int H) {
-    OriRec o;
-    const int area = x * y;
-    const uint32_t valid = (x >= 1 && y >= 1 && x <= W && y <= L) ? 1u : 0u;
-    const uint32_t big = (x > kTileX || y > kTileY) ? 1u : 0u;
-    const uint32_t hz1 = (uint32_t)max(H - z + 1, 0);
-    o.a = (uint32_t)x | ((uint32_t)y << 8) | (hz1 << 16) | (big << 25) | (valid << 26);
-    o.b = (uint32_t)(19 * area / 20 + 1) | ((uint32_t)(17 * area / 20 + 1) << 16);
-    o.c = (uint32_t)(area / 2 + 1) | ((uint32_t)((W - x) & 255) << 16) | ((uint32_t)((L - y) & 255) << 24);
-    // ceil(2^22 / nj): t / nj == (t * d) >> 22 for every t < 1024, nj <= 256 (t * d < 2^32, d < 2^24: one
-    // full-rate 24-bit multiply; exhaustively checked in tests/test_host_logic.py)
-    o.d = ((1u << kCandShift) + (uint32_t)(L - y + 1) - 1u) / (uint32_t)max(L - y + 1, 1);
-    return o;
-}
-
-template <int W, int L, int K, bool ROT, int MODE>
-__global__ __launch_bounds__(kWave * kMaxFastWavesPerBlock) void bpp_fast_kernel(const Params p) {
-    // W == 0 selects the runtime-geometry instantiation: sizes come from the launch parameters and the
-    // divisions below use their precomputed magic numbers; with W, L > 0 everything folds to constants.
-    constexpr bool RT = (W == 0);
-    static_assert(RT || (W * L) % 4 == 0, "fast path needs W*L % 4 == 0");
-    const int Wv = RT ? p.W : W, Lv = RT ? p.L : L;
-    const int A = Wv * Lv, A4 = A / 4, M = ROT ? 2 * A : A, M4 = M / 4, PW = Lv + 1, PN = (Wv + 1) * (Lv + 1);
-    auto div_a4 = [&](int n) { return RT ? (int)p.divA4.div((uint32_t)n) : n / A4; };
-    auto div_m4 = [&](int n) { return RT ? (int)p.divM4.div((uint32_t)n) : n / M4; };
-    auto div_l = [&](int n) { return RT ? (int)p.divL.div((uint32_t)n) : n / Lv; };
-    auto div_w = [&](int n) { return RT ? (int)p.divW.div((uint32_t)n) : n / Wv; };
-    auto div_pww = [&](int n) { return RT ? (int)p.divPWW.div((uint32_t)n) : n / (PW + Wv); };
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wid = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;
-    const int blk_e0 = xcd_block(p.xcd_remap) * wpb * p.epw;       // first bin of this workgroup
-    const int e0 = blk_e0 + wid * p.epw;                           // first bin of this wave
-    const int nenv = max(0, min(p.epw, p.E - e0));                 // block barriers below: no early return
-    unsigned char *wb = smem + wid * p.lds_per_wave;
-    uint8_t *hm = wb;
-    uint32_t *hm32 = (uint32_t *)wb;
-    uint8_t *mk = wb + p.off_mk;
-    BinRec *rec = (BinRec *)(wb + p.off_rec);
-    OriRec *ori = (OriRec *)(wb + p.off_ori);  // [epw][2]
-    Ent<K> *P = (Ent<K> *)(wb + p.off_P);
-    const uint32_t hclamp = (uint32_t)p.H + 1u;  // heights above H all behave like H+1 (never feasible)
-
-    if (BPP_ABL(p, 16)) return;
-    // The deciding wave (wave 0) issues its per-bin loads first, so their latency overlaps the staging.
-    const int dec_nb = max(0, min(wpb * p.epw, p.E - blk_e0));
-    const int dec_e = blk_e0 + (lane < dec_nb ? lane : 0);
-    bpp_env_state st0;
-    int64_t act0 = 0;
-    if (MODE == kStep && wid == 0 && !BPP_ABL(p, 32)) {
-        st0 = p.state[dec_e];
-        act0 = p.actions[dec_e];
-    }
-
-    // ---- phase 1: stage heightmaps as bytes ------------------------------------------------------
-    if (MODE == kStep) {
-        const uint32_t *gh = (const uint32_t *)(p.hmap + (size_t)e0 * A);
-        for (int q = lane; q < (BPP_ABL(p, 64) ? 0 : nenv * A4); q += kWave) hm32[q] = gh[q];
-    } else if (MODE == kMaskHmap) {
-        const int4 *gh = (const int4 *)(p.hmap_in + (size_t)e0 * A);
-        for (int q = lane; q < nenv * A4; q += kWave) {
-            const int4 v = gh[q];
-            hm32[q] = min((uint32_t)v.x, 255u) | (min((uint32_t)v.y, 255u) << 8) | (min((uint32_t)v.z, 255u) << 16) |
-                      (min((uint32_t)v.w, 255u) << 24);
-        }
-    } else if (MODE == kMaskObs) {
-        for (int q = lane; q < nenv * A4; q += kWave) {
-            const int el = div_a4(q);
-            const float4 v = ((const float4 *)(p.obs_in + (size_t)(e0 + el) * 4 * A))[q - el * A4];
-            hm32[q] = min((uint32_t)(int)v.x, 255u) | (min((uint32_t)(int)v.y, 255u) << 8) |
-                      (min((uint32_t)(int)v.z, 255u) << 16) | (min((uint32_t)(int)v.w, 255u) << 24);
-        }
-    } else {
-        for (int q = lane; q < nenv * A4; q += kWave) hm32[q] = 0u;  // space.py:22
-    }
-    __syncthreads();  // wave 0 reads the other waves' tiles below
-
-    // ---- phase 2: per-bin scalar work, lane-per-bin, done by ONE wave for the whole workgroup ------
-    // A workgroup owns wpb * epw (<= 64) consecutive bins.  Wave 0 carries one bin per lane through the
-    // scalar chain (state, action, items, placement rule, reward, Monitor, next item) and leaves a
-    // record per bin in the owning wave's LDS area; the other waves wait at the barrier.  (Executing
-    // this chain redundantly in every wave, for only `epw` bins each, cost ~4x the VALU work of this phase.)
-    bool fin = false;
-    double fin_ret = 0.0, fin_ratio = 0.0;
-    int fin_len = 0;
-    if (wid == 0 && !BPP_ABL(p, 32)) {
-        const bool active = lane < dec_nb;
-        const int e = dec_e;
-        const int ow = lane >> p.epw_shift, oel = lane & (p.epw - 1);  // owning wave, bin within it
-        unsigned char *ob = smem + ow * p.lds_per_wave;
-        const uint8_t *ohm = ob + oel * A;
-        BinRec r;
-        r.item = 0;
-        r.place = 0;
-        r.flags = 0;
-        r.any = 0;
-        if (MODE == kStep) {
-            bpp_env_state st = st0;                                    // loaded before the tile was staged
-            const int64_t act = act0;
-            // binCreator.py:15-18: current / next / first-of-next-episode items come from the state record;
-            // the pool entries the NEXT step needs are fetched speculatively for both outcomes.
-            const int T = p.T;
-            int seq_n = st.seq + p.seq_stride;
-            seq_n = seq_n >= p.P ? seq_n - p.P : seq_n;
-            int seq_nn = seq_n + p.seq_stride;
-            seq_nn = seq_nn >= p.P ? seq_nn - p.P : seq_nn;
-            const uint32_t it_cur = st.item_cur, it_nxt = st.item_next, it_rst = st.item_reset;
-            const LookAheadAt la = look_ahead_at(p, st.seq, seq_n, seq_nn, st.cursor);
-            const uint32_t sp_ok = p.pool[la.ok], sp_f1 = p.pool[la.f1], sp_f2 = p.pool[la.f2];
-            const int ix = it_cur & 255, iy = (it_cur >> 8) & 255, iz = (it_cur >> 16) & 255;
-            const bool noop = act == BPP_ACTION_NOOP;                  // include/bpp_abi.h: the bin is left alone
-            int64_t idx = act;                                         // bin3D.py:96-105
-            const bool flag = ROT && idx > A;
-            if (flag) idx -= A;
-            const int x = flag ? iy : ix, y = flag ? ix : iy, z = iz;  // space.py:166-172
-            bool ok = active && idx >= 0 && idx < (int64_t)(Wv + 1) * Lv;
-            int lx = 0, ly = 0;
-            if (ok) {
-                lx = div_l((int)idx);                                  // space.py:153-156
-                ly = (int)idx - lx * Lv;
-                ok = (lx + x <= Wv) && (ly + y <= Lv);                 // space.py:112-115
-            }
-            int top = 0;
-            if (ok) {
-                const uint8_t *hb = ohm + lx * Lv + ly;
-                int mh = 0, ma = 0;                                    // space.py:127-129
-                if (x <= 5 && y <= 5) {
-                    // common item sizes: 25 predicated independent LDS reads instead of a divergent loop
-                    int v[5][5];
-#pragma unroll
-                    for (int a = 0; a < 5; ++a)
-#pragma unroll
-                        for (int b = 0; b < 5; ++b) v[a][b] = (a < x && b < y) ? (int)hb[a * Lv + b] : -1;
-#pragma unroll
-                    for (int a = 0; a < 5; ++a)
-#pragma unroll
-                        for (int b = 0; b < 5; ++b) mh = max(mh, v[a][b]);
-#pragma unroll
-                    for (int a = 0; a < 5; ++a)
-#pragma unroll
-                        for (int b = 0; b < 5; ++b) ma += (v[a][b] == mh);
-                } else {
-                    for (int a = 0; a < x; ++a)
-                        for (int b = 0; b < y; ++b) {
-                            const int v = hb[a * Lv + b];
-                            ma = v > mh ? 1 : ma + (v == mh);
-                            mh = max(mh, v);
-                        }
-                }
-                const int r00 = hb[0], r10 = hb[(x - 1) * Lv], r01 = hb[y - 1], r11 = hb[(x - 1) * Lv + y - 1];
-                const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125
-                Win w;
-                w.mh = mh;
-                w.ma = ma;
-                w.c = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);
-                w.sc = (r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm);
-                ok = feasible(w, x * y, z, p.H, BPP_RULE_SPACE);       // space.py:131-144
-                top = mh + z;                                          // space.py:42-45 with lz = max_h
-            }
-            const int vol = ix * iy * iz;
-            const double rew = ok ? ((double)vol / p.binvol) * 10.0 : 0.0;  // bin3D.py:44-46,108-121
-            st.n_boxes += ok ? 1 : 0;
-            st.vol_sum += ok ? vol : 0;
-            st.ep_ret = st.ep_ret + rew;                               // bench/monitor.py:58-62
-            st.ep_len += noop ? 0 : 1;
-            const double ratio = (double)st.vol_sum / p.binvol;        // space.py:146-151
-            if (active) {
-                p.reward[e] = (float)rew;                              // acktr/envs.py:192
-                p.done[e] = (ok || noop) ? 0 : 1;
-                if (p.host_reward) {
-                    p.host_reward[e] = (float)rew;
-                    p.host_done[e] = (ok || noop) ? 0 : 1;
-                }
-                p.counter[e] = st.n_boxes;                             // bin3D.py:111,124
-                p.ratio[e] = ratio;
-                p.ep_ret[e] = st.ep_ret;
-                p.ep_len[e] = st.ep_len;
-            }
-            fin = active && !ok && !noop;
-            fin_ret = st.ep_ret;
-            fin_ratio = ratio;
-            fin_len = st.ep_len;
-            if (ok) {
-                st.cursor += 1;                                        // bin3D.py:116-117
-                st.item_cur = it_nxt;
-                st.item_next = sp_ok;
-                st.hmax = max(st.hmax, (uint32_t)top);                 // highest cell of the bin
-                r.item = it_nxt;
-                r.place = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
-                r.flags = 1u | ((uint32_t)top << 8);
-            } else if (noop) {
-                r.item = it_cur;
-            } else {                                                   // shmem_vec_env.py:128-129
-                st.episode += 1;
-                st.seq = seq_n;
-                st.cursor = 0;
-                st.n_boxes = 0;
-                st.vol_sum = 0;
-                st.ep_ret = 0.0;
-                st.ep_len = 0;
-                st.item_cur = it_rst;
-                st.item_next = sp_f1;
-                st.item_reset = sp_f2;
-                st.hmax = 0;
-                r.item = it_rst;
-                r.flags = 2u;
-            }
-            if (active) p.state[e] = st;
-            if (active && p.cache != nullptr) row_cache_drop(p, e);
-        } else if (MODE == kResetInit || MODE == kResetAdvance) {
-            bpp_env_state st;
-            if (MODE == kResetInit) {
-                st.episode = 0;
-                st.seq = (int32_t)(((uint32_t)p.base_mod + (uint32_t)e) % (uint32_t)p.P);
-            } else {
-                st = p.state[e];
-                st.episode += 1;
-                const int sq = st.seq + p.seq_stride;
-                st.seq = sq >= p.P ? sq - p.P : sq;
-            }
-            st.cursor = 0;
-            st.n_boxes = 0;
-            st.vol_sum = 0;
-            st.ep_ret = 0.0;
-            st.ep_len = 0;
-            int sn = st.seq + p.seq_stride;
-            sn = sn >= p.P ? sn - p.P : sn;
-            st.item_cur = p.pool[(size_t)st.seq * p.T + p.ring2];
-            st.item_next = p.pool[(size_t)st.seq * p.T + p.ring2 + min(1, p.T - 1 - p.ring2)];
-            st.item_reset = p.pool[(size_t)sn * p.T + p.ring2];
-            st.hmax = 0;
-            if (active) p.state[e] = st;
-            if (active && p.cache != nullptr) row_cache_drop(p, e);
-            r.item = st.item_cur;
-            r.flags = 2u;
-        } else if (MODE == kMaskObs) {
-            const float *o = p.obs_in + (size_t)e * 4 * A;             // acktr/utils.py:43-45
-            r.item = pack_item((int)o[A], (int)o[2 * A], (int)o[3 * A]);
-        } else {
-            const int32_t *it = p.items_in + (size_t)e * 3;
-            r.item = pack_item(it[0], it[1], it[2]);
-        }
-        if (active) {
-            ((BinRec *)(ob + p.off_rec))[oel] = r;
-            OriRec *oo = (OriRec *)(ob + p.off_ori) + oel * 2;
-            const int nx = r.item & 255u, ny = (r.item >> 8) & 255u, nz = (r.item >> 16) & 255u;
-            oo[0] = make_ori(Wv, Lv, nx, ny, nz, p.H);
-            if (ROT) oo[1] = make_ori(Wv, Lv, ny, nx, nz, p.H);          // utils.py:81-84
-        }
-    }
-    __syncthreads();
-    // episode statistics (main.py:159-162): off the other waves' critical path, after the barrier
-    if (MODE == kStep && wid == 0 && p.ep_acc && fin && !BPP_ABL(p, 128))
-        episode_acc_add(p.ep_acc, dec_e, fin_ret, fin_ratio, fin_len);
-
-    if (MODE == kStep) {
-        // ---- phase 2b: every wave applies its bins' placements (space.py:36-46: window := max_h + z),
-        // one sub-group of 64/epw lanes per bin, rows split over the sub-group ---------------------
-        const int G = kWave >> p.epw_shift;
-        const int el = lane >> (6 - p.epw_shift), sl = lane & (G - 1);
-        if (el < nenv) {
-            const BinRec r = rec[el];
-            if (r.flags & 1u) {
-                const int lx = r.place & 255u, ly = (r.place >> 8) & 255u, x = (r.place >> 16) & 255u, y = r.place >> 24;
-                uint8_t *hb = hm + el * A + lx * Lv + ly;
-                const uint8_t top = (uint8_t)(r.flags >> 8);
-                for (int a = sl; a < x; a += G)
-                    for (int b = 0; b < y; ++b) hb[a * Lv + b] = top;
-            }
-        }
-        wave_sync();
-    }
-
-    auto write_obs = [&]() {
-        uint32_t *gh = (uint32_t *)(p.hmap + (size_t)e0 * A);
-        float4 *go = (float4 *)(p.obs + (size_t)e0 * 4 * A);
-        for (int q = lane; q < nenv * A4; q += kWave) {
-            const int el = div_a4(q);
-            const uint32_t v = hm32[q];
-            gh[q] = v;
-            go[q + el * (3 * A4)] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u),
-                                                (float)(v >> 24));
-        }
-        // planes x, y, z are constants per bin (bin3D.py:49-53): bin-uniform passes, the value comes from a
-        // scalar register and every lane keeps one fixed offset
-        for (int el = 0; el < nenv; ++el) {
-            const uint32_t item = __builtin_amdgcn_readfirstlane(rec[el].item);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const float f = (float)((item >> (8 * pl)) & 255u);
-                const float4 v = make_float4(f, f, f, f);
-                float4 *gp = go + el * A + (pl + 1) * A4;
-                for (int k = lane; k < A4; k += kWave) gp[k] = v;
-            }
-        }
-    };
-
-    if (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) {
-        if (MODE == kStep) {
-            // ---- phase 3a: finished bins restart from an empty map --------------------------------
-            for (int q = lane; q < nenv * A4; q += kWave)
-                if (rec[div_a4(q)].flags & 2u) hm32[q] = 0u;
-            wave_sync();
-        }
-        // ---- phase 3b: byte heightmap (state) + float32 observation out (bin3D.py:49-66) ----------
-        if (!BPP_ABL(p, 8)) write_obs();
-        if (p.mask == nullptr) return;
-    }
-
-    // ---- phase 4a: prefix image of the height-level codes ------------------------------------------
-    bool built = false;
-    if constexpr (!RT) {
-        if (!BPP_ABL(p, 1) && p.epw == 1 && W * 2 <= kWave) {
-            if (nenv > 0) build_prefix_one_bin<W, L, K>(hm, P, hclamp, lane);
-            built = true;
-        }
-    }
-    if (!built && !BPP_ABL(p, 1)) {
-        Ent<K> zero;
-#pragma unroll
-        for (int k = 0; k < K; ++k) zero.w[k] = 0;
-        for (int t = lane; t < nenv * (PW + Wv); t += kWave) {         // row 0 and column 0
-            const int el = div_pww(t), r = t - el * (PW + Wv);
-            P[el * PN + (r < PW ? r : (r - PW + 1) * PW)] = zero;
-        }
-        for (int t = lane; t < nenv * Wv; t += kWave) {                // running sums along each row
-            const int el = div_w(t), i = t - el * Wv;
-            const uint8_t *row = hm + el * A + i * Lv;
-            Ent<K> *pr = P + el * PN + (i + 1) * PW + 1;
-            Ent<K> s = zero;
-            if constexpr (!RT) {
-                uint32_t hv[L > 0 ? L : 1];
-#pragma unroll
-                for (int j = 0; j < L; ++j) hv[j] = row[j];
-#pragma unroll
-                for (int j = 0; j < L; ++j) {
-                    const Ent<K> c = code_of<K>(min(hv[j], hclamp));
-#pragma unroll
-                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
-                    pr[j] = s;
-                }
-            } else {
-                for (int j = 0; j < Lv; ++j) {
-                    const Ent<K> c = code_of<K>(min((uint32_t)row[j], hclamp));
-#pragma unroll
-                    for (int k = 0; k < K; ++k) s.w[k] += c.w[k];
-                    pr[j] = s;
-                }
-            }
-        }
-        wave_sync();
-        for (int t = lane; t < nenv * Lv; t += kWave) {                // then down each column
-            const int el = div_l(t), j = t - el * Lv;
-            Ent<K> *pc = P + el * PN + PW + (j + 1);
-            Ent<K> s = zero;
-            if constexpr (!RT) {
-                constexpr int CH = W % 10 == 0 ? 10 : (W % 5 == 0 ? 5 : 1);
-                for (int i0 = 0; i0 < W; i0 += CH) {
-                    Ent<K> v[CH];
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) v[i] = pc[(i0 + i) * PW];
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) s.w[k] += v[i].w[k];
-                        pc[(i0 + i) * PW] = s;
-                    }
-                }
-            } else {
-                for (int i = 0; i < Wv; ++i) {
-                    const Ent<K> v = pc[i * PW];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) s.w[k] += v.w[k];
-                    pc[i * PW] = s;
-                }
-            }
-        }
-        wave_sync();
-    }
-
-    // ---- phase 4b: feasibility of every candidate position (acktr/utils.py:37-94) ----------------
-    // Bin-uniform evaluation: the wave walks its bins (and orientations) one after the other, so the
-    // item constants live in scalar registers, and only the (W-x+1)*(L-y+1) in-range candidates
-    // (utils.py:54-55 loop ranges) are enumerated -- lane t <-> (i, j) = (t / nj, t % nj).
-    for (int g = lane; g < nenv * M4; g += kWave) ((uint32_t *)mk)[g] = 0u;
-    wave_sync();
-    for (int el = 0; el < (BPP_ABL(p, 2) ? 0 : nenv); ++el) {
-        unsigned long long any = 0ull;
-        const Ent<K> *Pe = P + el * PN;
-        const uint8_t *he = hm + el * A;
-        uint8_t *me = mk + el * M;
-        // a bin that was just reset shows an empty map: its mask is the in-range rectangle (no lookups)
-        const bool fresh = (MODE == kStep || MODE == kResetInit || MODE == kResetAdvance) &&
-                           (__builtin_amdgcn_readfirstlane(rec[el].flags) & 2u) != 0u;
-#pragma unroll
-        for (int rot = 0; rot < (ROT ? 2 : 1); ++rot) {                // utils.py:81-89: second half
-            const OriRec ov = ori[el * 2 + rot];
-            const uint32_t oa = __builtin_amdgcn_readfirstlane(ov.a), ob = __builtin_amdgcn_readfirstlane(ov.b),
-                           oc = __builtin_amdgcn_readfirstlane(ov.c), od = __builtin_amdgcn_readfirstlane(ov.d);
-            if (!(oa & (1u << 26))) continue;                          // item does not fit at all
-            const int x = oa & 255u, y = (oa >> 8) & 255u, hz1 = (oa >> 16) & 511u;
-            if (ROT && rot == 1 && x == y) {
-                // square footprint: the turned item's mask (utils.py:81-89) equals the first half
-                for (int g = lane; g < A4; g += kWave) ((uint32_t *)me)[A4 + g] = ((const uint32_t *)me)[g];
-                continue;
-            }
-            const bool big = (oa >> 25) & 1u;
-            const int nj = (int)(oc >> 24) + 1, nv = ((int)((oc >> 16) & 255u) + 1) * nj;
-            const int t95 = ob & 0xffffu, t85 = ob >> 16, t50 = oc & 0xffffu;
-            const int o10 = (x - 1) * Lv, o01 = y - 1;
-            // one candidate loop per case, so that no bin-uniform condition is re-tested per candidate
-            auto run = [&](auto big_c, auto empty_c) {
-                constexpr bool BIG = decltype(big_c)::value, EMPTY = decltype(empty_c)::value;
-#pragma unroll 2
-                for (int t = lane; t < nv; t += kWave) {
-                    const int i = (int)(((uint32_t)t * od) >> kCandShift), j = t - i * nj;
-                    bool f;
-                    if (EMPTY) {
-                        f = hz1 > 0;  // empty map: max_h = 0 over the whole window, every in-range position passes
-                    } else {
-                        const Ent<K> *Pb = Pe + i * PW + j;
-                        int mh, ma;
-                        if (!BIG) {
-                            const Ent<K> a = Pb[0], b = Pb[y], cc = Pb[x * PW], d = Pb[x * PW + y];
-                            Ent<K> h;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) h.w[k] = (a.w[k] + d.w[k]) - (b.w[k] + cc.w[k]);
-                            top_of<K>(h, mh, ma);
-                        } else {
-                            window_top<K>(Pe, PW, i, j, x, y, mh, ma);
-                        }
-                        const uint8_t *hb = he + i * Lv + j;
-                        const int r00 = hb[0], r10 = hb[o10], r01 = hb[o01], r11 = hb[o10 + o01];
-                        const int cnt = (r00 == mh) + (r10 == mh) + (r01 == mh) + (r11 == mh);  // utils.py:23-26
-                        const int thr = cnt == 4 ? t50 : (cnt == 3 ? t85 : t95);
-                        f = (mh < hz1) && (ma >= thr);                 // utils.py:20-33
-                        if (p.rule == BPP_RULE_SPACE) {                // space.py:122-125: sc >= 3
-                            const int rm = max(max(r00, r10), max(r01, r11));
-                            f = f && ((r00 == rm) + (r10 == rm) + (r01 == rm) + (r11 == rm) >= 3);
-                        }
-                    }
-                    me[rot * A + i * Lv + j] = f ? 1 : 0;
-                    any |= __ballot(f);
-                }
-            };
-            using T = std::true_type;
-            using F = std::false_type;
-            if (fresh)
-                run(F{}, T{});
-            else if (big)
-                run(T{}, F{});
-            else
-                run(F{}, F{});
-        }
-        if (any != 0ull && lane == 0) rec[el].any = 1u;
-    }
-    wave_sync();
-
-    // ---- phase 4c (optional): draw the next action uniformly among the feasible entries ------------
-    // Same result as bpp_sample_feasible on the mask this step writes: one sub-group of 64/epw lanes per
-    // bin; a lane owns `per` consecutive dwords (4 mask bytes each) of the bin's LDS mask, byte sums come
-    // from one multiply (bytes are 0/1), an inclusive scan inside the sub-group locates the lane holding
-    // the pick-th set entry (pick = hash * count >> 32) and prefix-byte compares locate it in the dword.
-    if (MODE == kStep && p.next_action != nullptr) {
-        const int NQ = M4;
-        const int G = kWave >> p.epw_shift;
-        const int el = lane >> (6 - p.epw_shift), sl = lane & (G - 1);
-        const bool act = el < nenv;
-        const int per = (NQ + G - 1) / G;
-        const uint32_t *mq = (const uint32_t *)mk + (act ? el : 0) * NQ;
-        const bool anyf = act && rec[act ? el : 0].any != 0u;
-        int cnt = 0;
-        for (int k = 0; k < per; ++k) {
-            const int q = sl * per + k;
-            const uint32_t v = (act && q < NQ) ? (anyf ? mq[q] : 0x01010101u) : 0u;
-            cnt += (int)((v * 0x01010101u) >> 24);
-        }
-        int incl = cnt;
-        for (int d = 1; d < G; d <<= 1) {
-            const int o = __shfl_up(incl, d, kWave);
-            if (sl >= d) incl += o;
-        }
-        const int total = __shfl(incl, lane | (G - 1), kWave);
-        const int e = e0 + el;
-        int rem = (int)__umulhi(mix32(mix32_base(p.sample_seed, p.sample_step), (uint32_t)(p.env_id_base + e)), (uint32_t)total) -
-                  (incl - cnt);
-        if (act && total > 0 && rem >= 0 && rem < cnt) {
-            int found = 0;
-            for (int k = 0; k < per; ++k) {
-                const int q = sl * per + k;
-                const uint32_t v = q < NQ ? (anyf ? mq[q] : 0x01010101u) : 0u;
-                const uint32_t cum = v * 0x01010101u;          // byte t = number of set entries among bytes 0..t
-                const int c = (int)(cum >> 24);
-                if (rem >= 0 && rem < c) {
-                    // first byte whose running count exceeds rem
-                    const uint32_t r = (uint32_t)rem;
-                    found = q * 4 + (int)(((cum & 255u) <= r) + (((cum >> 8) & 255u) <= r) + (((cum >> 16) & 255u) <= r));
-                }
-                rem -= c;
-            }
-            p.next_action[e] = found;
-        }
-    }
-
-    // ---- phase 5: float32 mask out, all-ones fallback (utils.py:59-60,91-92) ---------------------
-    {
-        float4 *gm = (float4 *)(p.mask + (size_t)e0 * M);
-        for (int g = lane; g < (BPP_ABL(p, 4) ? 0 : nenv * M4); g += kWave) {
-            const uint32_t v = rec[div_m4(g)].any ? ((const uint32_t *)mk)[g] : 0x01010101u;
-            gm[g] = make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
-        }
-    }
-}
-
+#include "bpp_rt_kernels.inl"
 #include "bpp_tile_kernel.inl"
 #include "bpp_stream_gen.inl"
 
-// Sub-groups of 16 lanes per bin (4 bins per wave): each lane owns `per` consecutive float4 quads of
-// the bin's mask row (16-byte loads), an inclusive scan inside the 16-lane row locates the pick-th set
-// entry in index order.  pick = (hash >> 32) * count >> 32.
-template <int PER>
-__global__ __launch_bounds__(256) void sample_kernel(const float *mask, int64_t *actions, int E, int M,
-                                                     int64_t env_id_base, uint64_t seed, uint64_t step) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = tid >> 4, sl = threadIdx.x & 15;
-    const bool active = e < E;
-    const float4 *m = (const float4 *)(mask + (size_t)(active ? e : 0) * M);
-    const int nq = M >> 2;
-    float4 q[PER];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int qi = sl * PER + k;
-        q[k] = (active && qi < nq) ? m[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-        cnt += (q[k].x != 0.f) + (q[k].y != 0.f) + (q[k].z != 0.f) + (q[k].w != 0.f);
-    }
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        const int o = __shfl_up(incl, d, 16);
-        if (sl >= d) incl += o;
-    }
-    const int total = __shfl(incl, 15, 16);
-    if (!active) return;
-    if (total == 0) {
-        if (sl == 0) actions[e] = 0;
-        return;
-    }
-    int pick = (int)__umulhi(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)), (uint32_t)total);
-    const int excl = incl - cnt;
-    if (pick >= excl && pick < incl) {
-        pick -= excl;
-        int found = 0, c = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const float v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (v[t] != 0.f) {
-                    if (c == pick) found = (sl * PER + k) * 4 + t;
-                    ++c;
-                }
-        }
-        actions[e] = found;
-    }
-}
+#include "bpp_heads.inl"
+#include "bpp_stats.inl"
 
-// Masked categorical action selection (include/bpp_abi.h: bpp_masked_act; acktr/distributions.py:71-84,
-// acktr/model.py:56-68).  16 lanes per bin = one DPP row, PER float4 quads of logits and mask per lane (lane sl owns quads
-// sl, sl + 16, ...: every load instruction of a row is one contiguous 256-byte segment).  Round 6: the kernel is VALU-issue
-// bound, not memory bound -- 65 536 rows of M = 100 are 16 waves per SIMD, and round 1's 680 instructions per wave
-// (38 ds_bpermute shuffles with their address arithmetic, two IEEE divisions, logf, per-element range predicates) were 16.2 us
-// for 53 MB.  Now: row maximum, softmax denominator, probability total, the inclusive scan of the CDF and the index
-// reductions run on the DPP data path (row_ror / row_shr: one VALU instruction each, no LDS), the reciprocals and the
-// logarithm are the hardware's (v_rcp_f32 / v_log_f32, 1 ulp: far inside the 5e-6 log-probability tolerance the torch
-// reference is held to), a quad past the end of the row is a -inf logit instead of a predicate per element, the sampled
-// entry is found by COUNTING the cumulative sums below the target, and the lane that owns the chosen entry writes the outputs
-// (no broadcast of its probability): ~340 instructions per wave.
-// row_ror:n rotates within every 16-lane row; row_shr:n shifts, lanes without a source keep `old`
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v, float old) {
-    (void)old;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v, int old) {
-    (void)old;
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0x128>(v, v)); v = fmaxf(v, dpp_f<0x124>(v, v)); v = fmaxf(v, dpp_f<0x122>(v, v)); v = fmaxf(v, dpp_f<0x121>(v, v));
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f<0x128>(v, v); v += dpp_f<0x124>(v, v); v += dpp_f<0x122>(v, v); v += dpp_f<0x121>(v, v);
-    return v;
-}
-__device__ __forceinline__ int row16_min(int v) {
-    v = min(v, dpp_i<0x128>(v, v)); v = min(v, dpp_i<0x124>(v, v)); v = min(v, dpp_i<0x122>(v, v)); v = min(v, dpp_i<0x121>(v, v));
-    return v;
-}
-__device__ __forceinline__ int row16_isum(int v) {
-    v += dpp_i<0x128>(v, v); v += dpp_i<0x124>(v, v); v += dpp_i<0x122>(v, v); v += dpp_i<0x121>(v, v);
-    return v;
-}
-__device__ __forceinline__ float row16_scan(float v) {   // inclusive prefix sum along the row
-    v += dpp_f<0x111>(v, 0.0f); v += dpp_f<0x112>(v, 0.0f); v += dpp_f<0x114>(v, 0.0f); v += dpp_f<0x118>(v, 0.0f);
-    return v;
-}
-
-template <int PER, bool DET>
-__global__ __launch_bounds__(256) void masked_act_kernel(const float *logits, const float *mask, int64_t *action,
-                                                         float *log_prob, int E, int M, int64_t env_id_base,
-                                                         uint64_t seed, uint64_t step, const uint64_t *seed_step) {
-    if (seed_step != nullptr) seed = seed_step[0], step = seed_step[1];   // bpp_masked_act_counter: (seed, step) live in device memory
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = tid >> 4, sl = threadIdx.x & 15;
-    const bool active = e < E;
-    const size_t row = (size_t)(active ? e : 0) * M;
-    const float4 *xq = (const float4 *)(logits + row), *mq = (const float4 *)(mask + row);
-    const int nq = M >> 2;
-    float4 xv[PER], mv[PER];
-    bool in[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {      // every load of both operands is issued before any arithmetic
-        const int qi = sl + 16 * k;
-        in[k] = qi < nq;
-        // a quad past the end of the row behaves like four entries that can never be chosen: logit -inf (probability 0 before
-        // the floor), and the 1e-5 floor itself is switched off for it below
-        xv[k] = in[k] ? xq[qi] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        mv[k] = in[k] ? mq[qi] : make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-    float z[PER][4];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        z[k][0] = xv[k].x - (1.0f - mv[k].x) * 14.0f;  // distributions.py:76-79
-        z[k][1] = xv[k].y - (1.0f - mv[k].y) * 14.0f;
-        z[k][2] = xv[k].z - (1.0f - mv[k].z) * 14.0f;
-        z[k][3] = xv[k].w - (1.0f - mv[k].w) * 14.0f;
-        mx = fmaxf(fmaxf(mx, fmaxf(z[k][0], z[k][1])), fmaxf(z[k][2], z[k][3]));
-    }
-    mx = row16_max(mx);
-    const float mxl = mx * 1.44269504088896340736f;
-    float part = 0.0f;
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            z[k][t] = __builtin_amdgcn_exp2f(z[k][t] * 1.44269504088896340736f - mxl);   // exp(z - mx); exp2(-inf) = 0
-            part += z[k][t];
-        }
-    const float inv_sum = __builtin_amdgcn_rcpf(row16_sum(part));
-    float qtot[PER];
-    float lane_tot = 0.0f;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const float floor_k = in[k] ? 1e-5f : 0.0f;       // distributions.py:79-80
-        qtot[k] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            z[k][t] = z[k][t] * inv_sum + floor_k;
-            qtot[k] += z[k][t];
-        }
-        lane_tot += qtot[k];
-    }
-    const float tot = row16_sum(lane_tot);
-    int a;
-    if constexpr (DET) {     // dist.mode(): first index of the maximum
-        float best = -1.0f;
-        int best_i = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (z[k][t] > best) {
-                    best = z[k][t];
-                    best_i = (sl + 16 * k) * 4 + t;
-                }
-        const float rb = row16_max(best);
-        a = row16_min(best == rb ? best_i : 0x7fffffff);
-    } else {
-        // inverse CDF at u * total, entries in index order (quad-row k, then lane): the chosen entry is the first one whose
-        // inclusive cumulative sum exceeds the target = the NUMBER of entries whose cumulative sum does not (the sums of a
-        // lane grow with the index; the handful of cases where float32 rounding makes a lane's start fall an ulp below its
-        // predecessor's end move a draw by one entry whose cumulative sum equals the target to ~1e-7 -- inside the CDF
-        // tolerance the kernel is held to)
-        const float u = (float)(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + (active ? e : 0))) >> 8) * (1.0f / 16777216.0f);
-        const float target = u * tot;
-        float base = 0.0f;
-        int below = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const float incl = row16_scan(qtot[k]);
-            float c = base + incl - qtot[k];
-            int bk = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                c += z[k][t];
-                bk += c <= target ? 1 : 0;
-            }
-            below += in[k] ? bk : 0;
-            if (k + 1 < PER) base += row16_sum(qtot[k]);
-        }
-        a = min(row16_isum(below), M - 1);          // (every sum <= target: rounding at u ~ 1 -> last entry)
-    }
-    // the lane that owns entry `a` holds its probability: it writes both outputs
-    const int aq = a >> 2;
-    if (active && (aq & 15) == sl) {
-        float pa = 0.0f;
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if ((aq >> 4) == k) {
-                const int t = a & 3;
-                pa = t == 0 ? z[k][0] : (t == 1 ? z[k][1] : (t == 2 ? z[k][2] : z[k][3]));
-            }
-        action[e] = a;
-        if (log_prob) {
-            const float eps = 1.1920928955078125e-7f;  // torch clamp_probs: finfo(float32).eps
-            log_prob[e] = __logf(fminf(fmaxf(pa * __builtin_amdgcn_rcpf(tot), eps), 1.0f - eps));
-        }
-    }
-}
-
-// Same selection for rows the 16-lane kernel cannot take (M not a multiple of 4, or M > 512 such as the
-// 20x20 bin with rotation, M = 800): one wave per bin, entry k lives in lane k % 64, chunk k / 64; the CDF
-// walks the chunks in order with an inclusive wave scan per chunk.
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-    return v;
-}
-__global__ __launch_bounds__(256) void masked_act_kernel_generic(const float *logits, const float *mask, int64_t *action,
-                                                                 float *log_prob, int E, int M, int64_t env_id_base,
-                                                                 uint64_t seed, uint64_t step, int deterministic, const uint64_t *seed_step) {
-    if (seed_step != nullptr) seed = seed_step[0], step = seed_step[1];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= E) return;  // whole waves leave; no block-level synchronisation below
-    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
-    const int nchunk = (M + kWave - 1) / kWave;
-    float mx = -INFINITY;
-    for (int k = lane; k < M; k += kWave) mx = fmaxf(mx, x[k] - (1.0f - m[k]) * 14.0f);  // distributions.py:76-79
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
-    float part = 0.0f;
-    for (int k = lane; k < M; k += kWave) part += expf(x[k] - (1.0f - m[k]) * 14.0f - mx);
-    const float sum = wave_sum_f(part);
-    float lane_tot = 0.0f, best = -1.0f;
-    int best_i = 0;
-    for (int k = lane; k < M; k += kWave) {
-        const float pk = expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f;  // distributions.py:79-80
-        lane_tot += pk;
-        if (pk > best) {
-            best = pk;
-            best_i = k;
-        }
-    }
-    const float tot = wave_sum_f(lane_tot);
-    int a;
-    float pa;
-    if (deterministic) {  // dist.mode(): first index of the maximum
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const float ob = __shfl_xor(best, d, kWave);
-            const int oi = __shfl_xor(best_i, d, kWave);
-            if (ob > best || (ob == best && oi < best_i)) {
-                best = ob;
-                best_i = oi;
-            }
-        }
-        a = best_i;
-        pa = best;
-    } else {
-        const float u = (float)(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)) >> 8) * (1.0f / 16777216.0f);
-        const float target = u * tot;
-        float base = 0.0f, pm = 0.0f;
-        int cand = 0x7fffffff;
-        for (int c = 0; c < nchunk; ++c) {  // wave-uniform trip count
-            const int k = c * kWave + lane;
-            const float pk = k < M ? expf(x[k] - (1.0f - m[k]) * 14.0f - mx) / sum + 1e-5f : 0.0f;
-            float incl = pk;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const float o = __shfl_up(incl, d, kWave);
-                if (lane >= d) incl += o;
-            }
-            if (cand == 0x7fffffff && k < M && base + incl > target) {
-                cand = k;
-                pm = pk;
-            }
-            base += __shfl(incl, kWave - 1, kWave);
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const int oc = __shfl_xor(cand, d, kWave);
-            const float op = __shfl_xor(pm, d, kWave);
-            if (oc < cand) {
-                cand = oc;
-                pm = op;
-            }
-        }
-        if (cand == 0x7fffffff) {  // rounding at u ~ 1: the last entry
-            cand = M - 1;
-            pm = expf(x[M - 1] - (1.0f - m[M - 1]) * 14.0f - mx) / sum + 1e-5f;
-        }
-        a = cand;
-        pa = pm;
-    }
-    if (lane == 0) {
-        action[e] = a;
-        if (log_prob) {
-            const float eps = 1.1920928955078125e-7f;
-            log_prob[e] = logf(fminf(fmaxf(pa / tot, eps), 1.0f - eps));
-        }
-    }
-}
-
-// Training half of the masked policy head (acktr/distributions.py:71-101 as used by Policy.evaluate_actions,
-// acktr/model.py:90-96): for the actions taken, one wave per bin computes
-//   logp  = log(clamp(p[a]))            p = lx / sum(lx), lx = softmax(x - 14 (1 - mask)) + 1e-5   (dist.log_probs)
-//   ent   = -sum_k p_k log(clamp(p_k))                                                           (dist.entropy())
-//   bad   = sum_k softmax(x)_k (1 - mask_k)                                                      (row sum of `bx`)
-// and the backward kernel the gradient of  g_logp * logp + g_ent * ent + g_bad * bad  with respect to the logits
-// (clamp = torch's probs_to_logits clamp to [eps, 1 - eps], derivative 0 outside).
-struct RowStats {
-    float mq, ma, sq, sa, tot;   // maxima and denominators of the masked / plain softmax, sum of lx
-};
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, kWave));
-    return v;
-}
-__device__ __forceinline__ RowStats masked_row_stats(const float *x, const float *m, int M, int lane) {
-    RowStats r;
-    float mq = -INFINITY, ma = -INFINITY;
-    for (int k = lane; k < M; k += kWave) {
-        mq = fmaxf(mq, x[k] - (1.0f - m[k]) * 14.0f);
-        ma = fmaxf(ma, x[k]);
-    }
-    r.mq = wave_max_f(mq);
-    r.ma = wave_max_f(ma);
-    float sq = 0.0f, sa = 0.0f;
-    for (int k = lane; k < M; k += kWave) {
-        sq += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq);
-        sa += expf(x[k] - r.ma);
-    }
-    r.sq = wave_sum_f(sq);
-    r.sa = wave_sum_f(sa);
-    float tot = 0.0f;
-    for (int k = lane; k < M; k += kWave) tot += expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f;
-    r.tot = wave_sum_f(tot);
-    return r;
-}
-constexpr float kProbEps = 1.1920928955078125e-7f;   // torch.finfo(float32).eps, probs_to_logits clamp
-
-__global__ __launch_bounds__(256) void masked_eval_fwd_kernel(const float *logits, const float *mask, const int64_t *action,
-                                                              float *logp, float *entropy, float *bad, int E, int M) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= E) return;
-    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
-    const RowStats r = masked_row_stats(x, m, M, lane);
-    float h = 0.0f, b = 0.0f;
-    for (int k = lane; k < M; k += kWave) {
-        const float p = (expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot;
-        h -= p * logf(fminf(fmaxf(p, kProbEps), 1.0f - kProbEps));
-        b += expf(x[k] - r.ma) / r.sa * (1.0f - m[k]);
-    }
-    h = wave_sum_f(h);
-    b = wave_sum_f(b);
-    if (lane == 0) {
-        const int64_t a = action[e];
-        const float pa = (a >= 0 && a < M) ? (expf(x[a] - (1.0f - m[a]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot : kProbEps;
-        logp[e] = logf(fminf(fmaxf(pa, kProbEps), 1.0f - kProbEps));
-        entropy[e] = h;
-        bad[e] = b;
-    }
-}
-
-__global__ __launch_bounds__(256) void masked_eval_bwd_kernel(const float *logits, const float *mask, const int64_t *action,
-                                                              const float *g_logp, const float *g_ent, const float *g_bad,
-                                                              float *grad, int E, int M) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= E) return;
-    const float *x = logits + (size_t)e * M, *m = mask + (size_t)e * M;
-    float *g = grad + (size_t)e * M;
-    const RowStats r = masked_row_stats(x, m, M, lane);
-    const int64_t a = action[e];
-    const float gl = g_logp[e], ge = g_ent[e], gb = g_bad[e];
-    // h_k = dLoss/dp_k
-    auto hk = [&](int k, float p) {
-        const bool inside = p > kProbEps && p < 1.0f - kProbEps;
-        const float pc = fminf(fmaxf(p, kProbEps), 1.0f - kProbEps);
-        float h = -ge * (logf(pc) + (inside ? p / pc : 0.0f));
-        if (k == a) h += inside ? gl / pc : 0.0f;
-        return h;
-    };
-    float c = 0.0f, b = 0.0f;
-    for (int k = lane; k < M; k += kWave) {
-        const float p = (expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq + 1e-5f) / r.tot;
-        c += p * hk(k, p);
-        b += expf(x[k] - r.ma) / r.sa * (1.0f - m[k]);
-    }
-    c = wave_sum_f(c);   // sum_j p_j h_j
-    b = wave_sum_f(b);   // bad
-    float v = 0.0f;      // sum_j q_j u_j,  u_j = (h_j - c) / tot
-    for (int k = lane; k < M; k += kWave) {
-        const float q = expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq;
-        v += q * (hk(k, (q + 1e-5f) / r.tot) - c) / r.tot;
-    }
-    v = wave_sum_f(v);
-    for (int k = lane; k < M; k += kWave) {
-        const float q = expf(x[k] - (1.0f - m[k]) * 14.0f - r.mq) / r.sq;
-        const float u = (hk(k, (q + 1e-5f) / r.tot) - c) / r.tot;
-        const float av = expf(x[k] - r.ma) / r.sa;
-        g[k] = q * (u - v) + gb * av * ((1.0f - m[k]) - b);
-    }
-}
-
-// Fallback for rows that are not a multiple of 4 floats or longer than 16 * 8 quads: one wave per bin.
-__global__ __launch_bounds__(256) void sample_kernel_generic(const float *mask, int64_t *actions, int E, int M,
-                                                             int64_t env_id_base, uint64_t seed, uint64_t step) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= E) return;
-    const float *m = mask + (size_t)e * M;
-    const int per = (M + kWave - 1) / kWave;
-    const int b = min(lane * per, M), en = min(b + per, M);
-    int cnt = 0;
-    for (int k = b; k < en; ++k) cnt += (m[k] != 0.0f);
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int o = __shfl_up(incl, d, kWave);
-        if (lane >= d) incl += o;
-    }
-    const int total = __shfl(incl, kWave - 1, kWave);
-    if (total == 0) {
-        if (lane == 0) actions[e] = 0;
-        return;
-    }
-    int pick = (int)__umulhi(mix32(mix32_base(seed, step), (uint32_t)(env_id_base + e)), (uint32_t)total);
-    const int excl = incl - cnt;
-    if (pick >= excl && pick < incl) {
-        pick -= excl;
-        for (int k = b; k < en; ++k)
-            if (m[k] != 0.0f) {
-                if (pick == 0) {
-                    actions[e] = k;
-                    break;
-                }
-                --pick;
-            }
-    }
-}
-
-// Fixed-order reductions of the episode statistics (include/bpp_abi.h: BPP_REDUCE_LANES partial sums over strided
-// bins, then a binary tree; ONE workgroup, so the order -- and with it every bit of the four float64 sums that
-// multi-GPU jobs all-reduce -- is the same on every run and equals the oracle's).
-__device__ __forceinline__ void reduce_tree_1024(double s0, double s1, double s2, double s3, double *acc) {
-    static __shared__ double part[4][BPP_REDUCE_LANES];
-    const int t = threadIdx.x;
-    part[0][t] = s0;
-    part[1][t] = s1;
-    part[2][t] = s2;
-    part[3][t] = s3;
-    __syncthreads();
-    for (int d = BPP_REDUCE_LANES / 2; d > 0; d >>= 1) {
-        if (t < d) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) part[k][t] = part[k][t] + part[k][t + d];
-        }
-        __syncthreads();
-    }
-    if (t < 4) acc[t] = acc[t] + part[t][0];
-}
-
-// Stand-alone episode statistics (main.py:159-162) for callers that do not use bpp_batch.ep_acc.
-__global__ __launch_bounds__(BPP_REDUCE_LANES) void stats_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
-                                                                 const int32_t *ep_len, int E, double *acc) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int e = threadIdx.x; e < E; e += BPP_REDUCE_LANES)
-        if (done[e]) {
-            s0 = s0 + ep_ret[e];
-            s1 = s1 + ratio[e];
-            s2 = s2 + (double)ep_len[e];
-            s3 = s3 + 1.0;
-        }
-    reduce_tree_1024(s0, s1, s2, s3, acc);
-}
-
-// The same from the per-bin accumulator rows bpp_step keeps (bpp_batch.ep_acc).
-__global__ __launch_bounds__(BPP_REDUCE_LANES) void acc_reduce_kernel(double *ep_acc, int E, double *acc, int clear) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    // rows threadIdx.x, + 1024, + 2048, ... added in that order; eight rows are in flight at a time (the loads are
-    // independent, only the additions are ordered)
-    constexpr int U = 8;
-    int e = threadIdx.x;
-    for (; e + (U - 1) * BPP_REDUCE_LANES < E; e += U * BPP_REDUCE_LANES) {
-        double v[U][4];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double *a = (const double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
-            v[u][0] = a[0], v[u][1] = a[1], v[u][2] = a[2], v[u][3] = a[3];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            s0 = s0 + v[u][0];
-            s1 = s1 + v[u][1];
-            s2 = s2 + v[u][2];
-            s3 = s3 + v[u][3];
-            if (clear) {
-                double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)(e + u * BPP_REDUCE_LANES), 32);
-                a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
-            }
-        }
-    }
-    for (; e < E; e += BPP_REDUCE_LANES) {
-        double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
-        const double v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
-        s0 = s0 + v0;
-        s1 = s1 + v1;
-        s2 = s2 + v2;
-        s3 = s3 + v3;
-        if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
-    }
-    reduce_tree_1024(s0, s1, s2, s3, acc);
-}
-
-// The same reduction spread over the chip (bpp_episode_acc_reduce with a scratch buffer).  The normative order has 1 024
-// partial sums, each ONE sequential chain over its strided rows -- so 1 024 lanes is all the parallelism there is, and in
-// one workgroup they share one CU's memory pipeline (2 MB at ~30 GB/s).  Here every workgroup owns kAccWideLanes of the
-// partials (16 consecutive rows = one 512-byte line group per load instruction), fetches kAccWideRows rows of each at
-// once with all its threads, publishes its partials to the caller's scratch buffer and takes a ticket; the last arriver runs the binary
-// tree over all 1 024 partials.  Hand-off per MI355X_MICROARCH.md (inter-workgroup visibility): plain stores ->
-// __syncthreads -> lane-0 agent-scope release -> s_waitcnt vmcnt(0) -> relaxed agent atomic; consumer: agent-scope
-// acquire behind the ticket -> __syncthreads -> plain loads.
-#ifndef BPP_DRAIN_VMEM   // (the host emulator of tests/emu defines it away: there is no vector memory queue to drain)
-#define BPP_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // invisible to the compiler's waitcnt pass, which may drop its own
-#endif
-constexpr int kAccWideLanes = 16, kAccWideGroups = BPP_REDUCE_LANES / kAccWideLanes, kAccWideRows = 64;
-__global__ __launch_bounds__(256) void acc_reduce_wide_kernel(double *ep_acc, int E, double *acc, int clear, double *scratch) {
-    static __shared__ double part[4][BPP_REDUCE_LANES];
-    static __shared__ int last;
-    const int t = threadIdx.x;
-    unsigned int *ticket = (unsigned int *)(scratch + 4 * BPP_REDUCE_LANES);
-    // All 256 threads fetch: thread (j, l) = (t / 16, t % 16) brings rows j, j + 16, j + 32, j + 48 of a chunk of 64 rows of
-    // partial l into LDS (`part` is free until the tree) -- one memory latency per chunk instead of one per kAccWideU rows
-    // of a lane's own chain; then 64 threads, one per (partial, component), add the chunk's 64 values IN ROW ORDER: the same
-    // additions in the same order as the one-workgroup kernel (a row beyond E is read as +0.0, which changes no sum that
-    // started from +0.0).
-    {
-        double (*rows)[kAccWideLanes][4] = (double (*)[kAccWideLanes][4]) & part[0][0];     // [64][16][4] = 32 KB
-        const int l = t % kAccWideLanes, j = t / kAccWideLanes;
-        const int r = blockIdx.x * kAccWideLanes + l;
-        const int al = t / 4 % kAccWideLanes, ak = t % 4;      // adder thread t < 64: partial al, component ak
-        double sum = 0.0;
-        for (int e0 = 0; e0 < E; e0 += kAccWideRows * BPP_REDUCE_LANES) {
-            double v[kAccWideRows / 16][4];
-#pragma unroll
-            for (int m = 0; m < kAccWideRows / 16; ++m) {
-                const int e = e0 + (j + 16 * m) * BPP_REDUCE_LANES + r;
-                v[m][0] = v[m][1] = v[m][2] = v[m][3] = 0.0;
-                if (e < E) {
-                    double *a = (double *)__builtin_assume_aligned(ep_acc + 4 * (size_t)e, 32);
-                    v[m][0] = a[0], v[m][1] = a[1], v[m][2] = a[2], v[m][3] = a[3];
-                    if (clear) a[0] = 0.0, a[1] = 0.0, a[2] = 0.0, a[3] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < kAccWideRows / 16; ++m)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) rows[j + 16 * m][l][k] = v[m][k];
-            __syncthreads();
-            if (t < 4 * kAccWideLanes) {
-#pragma unroll 8
-                for (int q = 0; q < kAccWideRows; ++q) sum = sum + rows[q][al][ak];
-            }
-            __syncthreads();
-        }
-        if (t < 4 * kAccWideLanes) scratch[ak * BPP_REDUCE_LANES + blockIdx.x * kAccWideLanes + al] = sum;
-    }
-    __syncthreads();
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        BPP_DRAIN_VMEM();
-        const unsigned int n = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = n == (unsigned int)(kAccWideGroups - 1);
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!last) return;
-    for (int i = t; i < 4 * BPP_REDUCE_LANES; i += 256) (&part[0][0])[i] = scratch[i];
-    __syncthreads();
-    for (int d = BPP_REDUCE_LANES / 2; d > 0; d >>= 1) {
-        for (int r = t; r < d; r += 256) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) part[k][r] = part[k][r] + part[k][r + d];
-        }
-        __syncthreads();
-    }
-    if (t < 4) acc[t] = acc[t] + part[t][0];
-    if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next (stream-ordered) call
-}
-
-// bpp_gather_finished: ordered compaction of the finished bins' per-bin outputs.  Workgroup w owns the bins [w * chunk, (w + 1) *
-// chunk) (chunk a multiple of 4 096; at most 64 workgroups) and needs no word from the others: it counts the finished bins in
-// front of its chunk itself (the `done` bytes before it: at most 64 KB per 65 536 bins, 16 bytes per load, resident in L2), then
-// compacts its own bins in rounds of 4 096 -- thread t of a round owns 16 consecutive bins; exclusive prefix of the per-thread
-// counts by wave shuffles + one LDS pass over the 4 waves.  One launch, no scratch, no hand-off between workgroups, output in
-// ascending bin order whatever the order the workgroups run in.  (Round 4 ran ONE workgroup of 1 024 threads over all bins: four
-// serial rounds of gathers at 65 536 bins, ~60 us on the device.)  Output: header + five arrays of n entries (include/bpp_abi.h);
-// entries beyond n (a caller whose count is wrong) are dropped, the header tells.
-constexpr int kGatherThreads = 256, kGatherRound = kGatherThreads * 16, kGatherMaxGroups = 64;
-__device__ __forceinline__ int nonzero_bytes(uint32_t v) {
-    const uint32_t t = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v;    // bit 7 of every byte that is not zero
-    return __popc(t & 0x80808080u);
-}
-// bpp_mark where the runtime has no stream memory operation: one thread, one system-scope store
-__global__ void mark_kernel(uint32_t *flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-__global__ __launch_bounds__(kGatherThreads) void compact_finished_kernel(const uint8_t *done, const double *ep_ret, const double *ratio,
-                                                                          const int32_t *ep_len, const int32_t *counter, int E,
-                                                                          unsigned char *out, int n, int chunk) {
-    constexpr int NW = kGatherThreads / 64;
-    static __shared__ int wave_tot[NW];
-    static __shared__ int wave_off[NW];
-    static __shared__ int total;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double *o_ret = (double *)(out + 32), *o_ratio = o_ret + n;
-    int32_t *o_len = (int32_t *)(o_ratio + n), *o_cnt = o_len + n, *o_bin = o_cnt + n;
-    const int c_lo = (int)blockIdx.x * chunk, c_hi = min(E, c_lo + chunk);
-    const bool aligned = (((uintptr_t)done) & 15u) == 0;
-    // ---- finished bins in front of this workgroup's chunk (c_lo is a multiple of 4 096)
-    int before = 0;
-    if (aligned) {
-        for (int i = t; i < c_lo / 16; i += kGatherThreads) {
-            const uint4 v = ((const uint4 *)done)[i];
-            before += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
-        }
-    } else {
-        for (int i = t; i < c_lo; i += kGatherThreads) before += done[i] != 0;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-    if (lane == 0) wave_tot[wave] = before;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) base += wave_tot[k];
-    __syncthreads();
-    // ---- this workgroup's own bins
-    for (int c0 = c_lo; c0 < c_hi; c0 += kGatherRound) {
-        const int e0 = c0 + t * 16;
-        uint32_t m = 0;
-        if (e0 + 16 <= c_hi && aligned) {
-            const uint4 v = *(const uint4 *)(done + e0);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) m |= ((w[q] >> (8 * k)) & 255u) ? 1u << (4 * q + k) : 0u;
-        } else {
-            for (int k = 0; k < 16; ++k)
-                if (e0 + k < c_hi && done[e0 + k]) m |= 1u << k;
-        }
-        const int cnt = __popc(m);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        if (t == 0) {
-            int s = 0;
-            for (int k = 0; k < NW; ++k) {
-                wave_off[k] = s;
-                s += wave_tot[k];
-            }
-            total = s;
-        }
-        __syncthreads();
-        int pos = base + wave_off[wave] + incl - cnt;
-        while (m) {
-            const int k = __ffs((int)m) - 1;
-            m &= m - 1;
-            const int e = e0 + k;
-            if (pos < n) {
-                o_ret[pos] = ep_ret[e];
-                o_ratio[pos] = ratio[e];
-                o_len[pos] = ep_len[e];
-                o_cnt[pos] = counter[e];
-                o_bin[pos] = e;
-            }
-            ++pos;
-        }
-        base += total;
-        __syncthreads();
-    }
-    if (blockIdx.x == gridDim.x - 1 && t < 8) ((int32_t *)out)[t] = t == 0 ? base : 0;   // the last chunk's running count is the total
-}
 // launch shape of the compaction: at most kGatherMaxGroups workgroups, chunks of whole rounds
 static inline void gather_shape(int E, int &groups, int &chunk) {
     const int rounds = (E + kGatherRound - 1) / kGatherRound;

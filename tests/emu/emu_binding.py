@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_kernels.hip")
 DEPS = [SRC, os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_tile_kernel.inl"), os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_tile_body.inl"),
-        os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_stream_gen.inl"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+        os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_stream_gen.inl"), os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_heads.inl"), os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_rt_kernels.inl"),
+        os.path.join(ROOT, "online-3d-bpp-drl_amd", "csrc", "bpp_stats.inl"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.join(ROOT, "include", "bpp_abi.h"), os.path.join(ROOT, "include", "bpp_gen.inl")]
 LIB = os.path.join(HERE, "libbpp_emu.so" if not os.environ.get("BPP_EMU_DEFINES") else
                    "libbpp_emu.so." + "".join(c if c.isalnum() else "_" for c in os.environ["BPP_EMU_DEFINES"]))
