@@ -419,12 +419,13 @@ struct Launch {
 struct TileGeoEntry {
     int W, L, K, epw, nit, nit_big, nit_big_rot;   // groups per wave of the step kernel: default / when the outputs of one launch
 };                                                 // exceed the 256 MiB Infinity Cache, without / with rotation (measured)
-// Round 6 (profiles/r6e_sweep_bins_by_tile_groups_*.txt, two boxes): with ONE group per wave a launch of 262 144 / 1 048 576 10x10 bins
-// costs 14 - 17 % more per bin than a 65 536-bin launch (146 - 152 us instead of 4 x 31.8; eight and more rounds of workgroups: the
-// later rounds' cold reads queue behind the earlier rounds' write streams), with two or four groups per wave it does not (128 - 132 /
-// 124 - 132 us; 1 048 576 bins: 477 - 494 / 466 - 475 us = 2.1 - 2.25 G env steps/s) -- fewer, longer workgroups whose loads all
-// go out before any of their stores.  With rotation two groups win (155 vs 162 us with four, 175 with one).
-constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1, 4, 2}, {20, 20, 1, 1, 1, 4, 4}, {20, 20, 2, 1, 1, 4, 4}, {10, 10, 2, 4, 1, 2, 2}};
+// Round 6 (profiles/r6e_sweep_bins_by_tile_groups_*.txt, r6k_*; four boxes): with ONE group per wave a launch of 262 144 / 1 048 576 10x10
+// bins costs 14 - 17 % more per bin than a 65 536-bin launch (146 - 152 us instead of 4 x 31.8; eight and more rounds of workgroups:
+// the later rounds' cold reads queue behind the earlier rounds' write streams), with two or four groups per wave it does not (128 -
+// 133 / 124 - 136 us; 1 048 576 bins: 477 - 515 / 466 - 532 us = 2.0 - 2.25 G env steps/s) -- fewer, longer workgroups whose loads all
+// go out before any of their stores.  Two and four groups are within +- 3 % of each other, box by box and run by run: two stay
+// (with rotation two win clearly: 155 vs 162 us with four, 175 with one).
+constexpr TileGeoEntry kTileGeo[] = {{10, 10, 1, 4, 1, 2, 2}, {20, 20, 1, 1, 1, 4, 4}, {20, 20, 2, 1, 1, 4, 4}, {10, 10, 2, 4, 1, 2, 2}};
 constexpr size_t kOutputsPastL3 = 300u * 1000u * 1000u;   // obs + mask bytes per launch
 constexpr int kNumTileGeo = sizeof(kTileGeo) / sizeof(kTileGeo[0]);
 constexpr int kRuntimeGeo = 100;  // l.fast == kRuntimeGeo (K = 1) or kRuntimeGeo + 1 (K = 2)
