@@ -121,11 +121,57 @@ class _RowHelper(object):
         return self.host[:4 * M].view("<f4")
 
 
+# Envs whose CURRENT observation buffer the per-row helpers may be handed rows of (weak references; BppVecEnv registers itself).
+# main.py:163-169 calls the helper once per row of the observation the env has just returned -- and the fused step kernel has
+# already written the mask of exactly those rows (rule U, acktr/utils.py:8-35: the env's default `mask_rule`).  For such a row
+# the helper hands back the env's own mask row: the whole [E, M] mask is fetched ONCE per lock-step (first helper call after a
+# step), every further row of that step costs a slice.  Anything else -- a row of an older step, a CPU tensor, an array, a tensor
+# the caller built -- takes the kernel path below.  The observation must not have been modified in place (the reference loop never
+# does); ROW_CACHE = False switches the shortcut off.
+ROW_CACHE = True
+ROW_CACHE_MAX_BINS = 4096          # beyond that one fetch of the whole mask costs more than the rows a caller can reasonably ask for
+_ENVS = []
+
+
+def register_env(env):
+    """Called by BppVecEnv's constructor."""
+    import weakref
+    _ENVS[:] = [r for r in _ENVS if r() is not None]
+    _ENVS.append(weakref.ref(env))
+
+
+def _env_mask_row(observation, W, L, H, rotation):
+    """int32 [M] row of the mask the env computed for this very observation row, or None."""
+    ptr = observation.data_ptr()
+    for ref in _ENVS:
+        env = ref()
+        res = getattr(env, "_res", None) if env is not None else None
+        if res is None or env.E > ROW_CACHE_MAX_BINS or getattr(env, "closed", False):
+            continue
+        if (env.W, env.L, env.H) != (W, L, H) or bool(env.can_rotate) != bool(rotation) or not env.compute_mask or env.mask_rule != _lib.RULE_UTILS:
+            continue
+        obs = res.obs
+        row_bytes = 16 * W * L
+        off = ptr - obs.data_ptr()
+        if off < 0 or off >= env.E * row_bytes or off % row_bytes or obs.device != observation.device:
+            continue
+        key = (env._serial, obs.data_ptr())
+        cached = getattr(env, "_mask_rows_host", None)
+        if cached is None or cached[0] != key:
+            cached = env._mask_rows_host = (key, res.mask.to(torch.int32).cpu().numpy())      # ONE fetch per lock-step (synchronises)
+        return cached[1][off // row_bytes]
+    return None
+
+
 def _row_mask(observation, container_size, rotation):
     """int32 ndarray [M]: the mask of ONE observation row, whatever it is handed (device row, CPU tensor, ndarray)."""
     W, L, H = (int(v) for v in container_size)
     if (torch.is_tensor(observation) and observation.device.type == "cuda" and observation.dtype == torch.float32
             and observation.is_contiguous() and observation.numel() == 4 * W * L and observation.data_ptr() % 16 == 0):
+        if ROW_CACHE and _ENVS:
+            row = _env_mask_row(observation, W, L, H, rotation)
+            if row is not None:
+                return row.copy()
         return _RowHelper.of(observation.device).row(observation, W, L, H, rotation).astype(np.int32)
     m = batched_mask_from_obs(observation, container_size, rotation)
     return m[0].to(torch.int32).cpu().numpy().reshape(-1)

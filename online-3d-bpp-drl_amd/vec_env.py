@@ -417,6 +417,8 @@ class BppVecEnv(object):
         self.monitor = None        # MonitorCsv (make_vec_envs with a log_dir): step_wait() appends the finished episodes' rows
         self._side = None          # bpp_side (rollout_uniform in streaming mode): created on first use
         self.closed = False
+        from . import masks as _masks
+        _masks.register_env(self)      # the per-row mask helpers may hand back this env's own mask rows (masks.ROW_CACHE)
 
     MAX_STAGING = 16     # page-locked host buffers (29 B per bin each) handed out at the same time, at most
     spin_wait = True     # step_wait() spins on the step's completion word (bpp_mark / bpp_wait_mark); False: hipStreamSynchronize
@@ -1026,6 +1028,7 @@ class BppVecEnv(object):
             bufs, _ = self._buffers()
             if self._res is None or self.fresh_outputs:
                 self._res = bufs
+            self._serial += 1          # (the output buffers change under whoever cached rows of them: masks.ROW_CACHE, LazyInfos)
             bufs["obs"].copy_(sd["obs"])
             if "mask" in sd and bufs["mask"] is not None:
                 bufs["mask"].copy_(sd["mask"])

@@ -662,6 +662,39 @@ def test_gpu_config0_shape_rs_16_envs_through_the_factory(bpp, oracle):
     assert len(episode_rewards) > 20
 
 
+@pytest.mark.parametrize("rot,fresh", [(False, True), (True, False)])
+def test_gpu_row_helpers_hand_back_the_envs_own_mask_rows(bpp, oracle, rot, fresh):
+    """masks.ROW_CACHE: a row of the observation the env has just returned gets the mask row the step kernel wrote for it (one
+    fetch of the [E, M] mask per lock-step); the same rows through the kernel path (ROW_CACHE off), rows of an OLDER step, a
+    CPU copy and a row the caller built all give the oracle's mask of that observation."""
+    import torch
+    from bpp_amd import masks
+    size, E = (10, 10, 10), 24
+    pool = bpp.sequences.cut2_pool(size, 64, seed=3)
+    env = bpp.BppVecEnv(E, size, enable_rotation=rot, pool=pool, fresh_outputs=fresh)
+    helper = bpp.get_rotation_mask if rot else (lambda o, s: np.array(bpp.get_possible_position(o, s), np.int32))
+    obs = env.reset()
+    older = None
+    for t in range(12):
+        want = oracle.mask_from_obs(obs.cpu().numpy(), size, rot).astype(np.int32)
+        fetched_before = getattr(env, "_mask_rows_host", (None,))[0]
+        rows = np.stack([helper(o, size) for o in obs])
+        np.testing.assert_array_equal(rows, want)
+        assert env._mask_rows_host[0] != fetched_before and env._mask_rows_host[0][0] == env._serial      # the cache answered, once
+        masks.ROW_CACHE = False
+        try:
+            np.testing.assert_array_equal(np.stack([helper(o, size) for o in obs[:5]]), want[:5])          # the kernel path
+        finally:
+            masks.ROW_CACHE = True
+        np.testing.assert_array_equal(helper(obs[3].cpu(), size), want[3])                               # a CPU row
+        np.testing.assert_array_equal(helper(obs[4].clone(), size), want[4])                             # a row of the caller's own
+        if older is not None and fresh:       # a row of the previous step's observation (its buffer is still ours: fresh outputs)
+            np.testing.assert_array_equal(helper(older[0][2], size), older[1][2])
+        older = (obs, want)
+        a = env.sample_feasible(seed=5, step=t)
+        obs, _, _, _ = env.step(a)
+
+
 def test_gpu_example_policy_in_the_loop_runs():
     """examples/rollout_with_policy.py: CNN policy -> bpp_masked_act -> step_tensors -> EpisodeStats, end to end."""
     import os
