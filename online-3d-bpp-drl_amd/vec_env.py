@@ -182,7 +182,11 @@ class LazyInfos(object):
         if self._live is None:
             self._check_fresh()
             r = self._res
-            self._live = (r.counter.cpu().numpy().copy(), r.ratio.cpu().numpy().copy())
+            if getattr(r, "_flat", None) is not None and hasattr(r, "host_scalars"):
+                h = r.host_scalars()          # ONE device-to-host copy of the 29-byte-per-bin scalar block + one synchronisation
+                self._live = (h["counter"].copy(), h["ratio"].copy())
+            else:
+                self._live = (r.counter.cpu().numpy().copy(), r.ratio.cpu().numpy().copy())
         return self._live
 
     def __len__(self):
