@@ -75,6 +75,46 @@ def test_emulated_kernels_replay_all_2100_trajectories(emu, case, rot, ckpt):
     replay(lambda pool, size, r, n: emu.EmuEnv(pool, size, r, n), load_golden(case))
 
 
+@pytest.mark.parametrize("case,rot,ckpt", CASES)
+def test_example_actor_is_the_reference_actor(oracle, case, rot, ckpt):
+    """examples/evaluate_checkpoint.py rebuilds the reference's CNNPro actor path from plain torch layers and maps the
+    checkpoint's keys onto it: on observations of real states its logits equal those of the reference's own Policy
+    (acktr/model.py:265-323 + dist.linear) loaded the reference's way -- bit for bit on the CPU (same ops, same order)."""
+    import sys
+    import types
+    import torch
+    from oracle import ref_shims
+    root = ref_shims.REF_COPY if ref_shims.copy_available() else (ref_shims.REFERENCE_ROOT if ref_shims.available() else None)
+    if root is None or not os.path.isfile(os.path.join(root, "pretrained_models", ckpt)):
+        pytest.skip("no reference tree with the checkpoints here")
+    ref_shims.install(root)
+    from acktr.model import Policy
+    import bpp_amd
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import evaluate_checkpoint as ev
+    path = os.path.join(root, "pretrained_models", ckpt)
+    M = 100 * (1 + rot)
+    args = types.SimpleNamespace(channel=4, container_size=(10, 10, 10), pallet_size=10, enable_rotation=rot, hidden_size=256, device="cpu")
+    state, _ = torch.load(path, map_location="cpu", weights_only=False)
+    pol = Policy((400,), bpp_amd.Discrete(M), base_kwargs={"recurrent": False, "hidden_size": 256, "args": args})
+    sd = {k.replace("module.", "").replace("add_bias.", "").replace("_bias", "bias"): v for k, v in state.items()}
+    pol.load_state_dict({k: (v.squeeze(-1) if v.dim() <= 3 else v) for k, v in sd.items()})
+    pol.eval()
+    actor = ev.load_actor(path, 10, M, "cpu")
+    env = oracle.OracleEnv(dataset_pool()[:64], (10, 10, 10), rot, 64)
+    obs, mask = env.reset()
+    for t in range(12):
+        o = torch.from_numpy(obs)
+        with torch.no_grad():
+            _, feat, _, _ = pol.base(o, None, None)
+            want = pol.dist.linear(feat)
+            got = actor(o)
+        assert torch.equal(got, want)
+        a = want.masked_fill(torch.from_numpy(mask) == 0, -1e9).argmax(1).numpy()
+        r = env.step(a)
+        obs, mask = r["obs"], r["mask"]
+
+
 class _GpuEnv(object):
     def __init__(self, bpp, pool, size, rot, n):
         self.env = bpp.BppVecEnv(n, size, enable_rotation=bool(rot), pool=pool)
