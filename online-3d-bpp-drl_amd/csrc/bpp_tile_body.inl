@@ -221,12 +221,24 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
                         }
                 }
                 // merge (max, count) over the bin's LPB lanes; every lane ends up with the window's pair
-#pragma unroll
-                for (int d = 1; d < LPB; d <<= 1) {
-                    const int m2 = __shfl_xor(mh, d, kWave), c2 = __shfl_xor(ma, d, kWave);
+                // (round 6: on the DPP data path -- quad_perm within a bin's four lanes, row_ror within its sixteen -- instead of
+                // ds_bpermute shuffles: this merge sits in the serial chain the other three waves wait for)
+                auto merge = [&](int m2, int c2) {
                     const int nm = max(mh, m2);
                     ma = (mh == nm ? ma : 0) + (m2 == nm ? c2 : 0);
                     mh = nm;
+                };
+                if constexpr (LPB == 4) {
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0xB1, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0x4E, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+                } else if constexpr (LPB == 16) {
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0x128, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0x128, 0xf, 0xf, true));  // row_ror:8
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0x124, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0x124, 0xf, 0xf, true));  // row_ror:4
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0x122, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0x122, 0xf, 0xf, true));  // row_ror:2
+                    merge(__builtin_amdgcn_update_dpp(0, mh, 0x121, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, ma, 0x121, 0xf, 0xf, true));  // row_ror:1
+                } else {
+#pragma unroll
+                    for (int d = 1; d < LPB; d <<= 1) merge(__shfl_xor(mh, d, kWave), __shfl_xor(ma, d, kWave));
                 }
                 const int r00 = hb[0], r10 = hb[(x - 1) * L], r01 = hb[y - 1], r11 = hb[(x - 1) * L + y - 1];
                 const int rm = max(max(r00, r10), max(r01, r11));      // space.py:117-125

@@ -13,7 +13,7 @@ for v in "$@"; do
   for cfg in "10:" "10rot:--rotation" "20:--size 20 20 20 --envs 32768 --pool 2048" "stream:--stream" "stream20:--stream --size 20 20 20 --envs 32768"; do
     case " ${AB_ONLY:-10 10rot 20} " in *" ${cfg%%:*} "*) ;; *) continue;; esac
     name=${cfg%%:*}; args=${cfg#*:}
-    python bench.py --no-cpu-baseline --steps 300 --warmup 50 $args > $O/ab_${v}_$name.json 2>> $O/ab.err
+    python bench.py --no-cpu-baseline --only-headline --no-parity --steps 300 --warmup 50 --gpu-seconds 1.5 $args > $O/ab_${v}_$name.json 2>> $O/ab.err
     python - <<PY
 import json
 try:
