@@ -398,14 +398,19 @@ __device__ __forceinline__ void window_top(const Ent<K> *Pb, int PW, int i, int 
 
 // Prefix image of ONE bin by a whole wave (used when a wave owns a single bin, e.g. the 20x20 bin
 // whose image is 7 KB): every row is split into SEG = 64/W segments so that W*SEG (60 of 64 for W = 20)
-// lanes scan concurrently; each lane scans its <= CS cells, the segment totals are exchanged with
-// __shfl_up and added as offsets.  Same for the column pass.  (With lane-per-row scans only W of 64 lanes
+// lanes scan concurrently; each lane scans its <= CS cells, the segment totals are handed up lane by lane
+// (wave_shr:1 on the DPP data path) and added as offsets.  Same for the column pass.  (With lane-per-row scans only W of 64 lanes
 // worked and this phase was 27 % of the 20^3 step.)
+// the entry of the lane below (lane 0: zero) on the DPP data path: wave_shr:1, two 32-bit halves per word
 template <int K>
-__device__ __forceinline__ Ent<K> shfl_up_ent(const Ent<K> &v, int d) {
+__device__ __forceinline__ Ent<K> lane_below_ent(const Ent<K> &v) {
     Ent<K> r;
 #pragma unroll
-    for (int k = 0; k < K; ++k) r.w[k] = (uint64_t)__shfl_up((unsigned long long)v.w[k], d, kWave);
+    for (int k = 0; k < K; ++k) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v.w[k], 0x138, 0xf, 0xf, true);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v.w[k] >> 32), 0x138, 0xf, 0xf, true);
+        r.w[k] = ((uint64_t)hi << 32) | lo;
+    }
     return r;
 }
 
@@ -438,9 +443,10 @@ __device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *
             s[c] = run;
         }
         Ent<K> off = zero;
+        Ent<K> t = run;
 #pragma unroll
         for (int d = 1; d < SR; ++d) {
-            const Ent<K> t = shfl_up_ent<K>(run, d);
+            t = lane_below_ent<K>(t);          // the segment total d lanes below (round 6: DPP instead of ds_bpermute)
             if (sg >= d) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) off.w[k] += t.w[k];
@@ -477,9 +483,10 @@ __device__ __forceinline__ void build_prefix_one_bin(const uint8_t *hm, Ent<K> *
             s[c] = run;
         }
         Ent<K> off = zero;
+        Ent<K> t = run;
 #pragma unroll
         for (int d = 1; d < SC; ++d) {
-            const Ent<K> t = shfl_up_ent<K>(run, d);
+            t = lane_below_ent<K>(t);          // the segment total d lanes below (round 6: DPP instead of ds_bpermute)
             if (sg >= d) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) off.w[k] += t.w[k];

@@ -152,7 +152,7 @@ static inline T shfl_xor(T v, int m, int width, int line) {
     const int l = lane_id(), base = l & ~(width - 1), s = l ^ m;
     return shfl(v, (s < base || s >= base + width) ? l : s, line);
 }
-// DPP (v_mov_b32_dpp): row_shl / row_shr / row_ror within a row of 16 lanes and quad_perm; a lane without a source reads 0
+// DPP (v_mov_b32_dpp): row_shl / row_shr / row_ror within a row of 16 lanes, quad_perm and wave_shr:1; a lane without a source reads 0
 // with bound_ctrl, else keeps `old`.  Every lane of the wave executes the instruction (the kernels use it with all lanes on).
 static inline int dpp(int old, int src, int ctrl, bool bound_ctrl, int line) {
     const int l = lane_id(), row = l & ~15, p = l & 15;
@@ -161,6 +161,7 @@ static inline int dpp(int old, int src, int ctrl, bool bound_ctrl, int line) {
     else if (ctrl >= 0x111 && ctrl <= 0x11f) s = p - (ctrl - 0x110) >= 0 ? row + p - (ctrl - 0x110) : -1;    // row_shr:n  lane p reads p - n
     else if (ctrl >= 0x121 && ctrl <= 0x12f) s = row + ((p - (ctrl - 0x120)) & 15);                         // row_ror:n  lane p reads (p - n) mod 16
     else if (ctrl >= 0 && ctrl < 0x100) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);                       // quad_perm
+    else if (ctrl == 0x138) s = l - 1;                                                                      // wave_shr:1  lane l reads l - 1 (lane 0: none)
     else abort();
     const int got = shfl(src, s < 0 ? l : s, line);
     return s < 0 ? (bound_ctrl ? 0 : old) : got;
