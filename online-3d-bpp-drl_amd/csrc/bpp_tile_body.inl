@@ -26,7 +26,9 @@ __global__ __launch_bounds__(kWave * kTileWaves) BPP_TILE_ATTR void BPP_TILE_NAM
             return;
         }
     }
-    const int blk_e0 = (CACHE ? xcd_block_of((int)blockIdx.x - p.ncopy, (int)gridDim.x - p.ncopy, p.xcd_remap) : xcd_block(p.xcd_remap)) * NB;   // first bin of this workgroup
+    // (the mask-only entry points have no deciding wave and no workgroup barrier: their workgroups may be launched with fewer waves)
+    const int wg_bins = (MODE == kMaskObs || MODE == kMaskHmap) ? (int)(blockDim.x >> 6) * NBW : NB;
+    const int blk_e0 = (CACHE ? xcd_block_of((int)blockIdx.x - p.ncopy, (int)gridDim.x - p.ncopy, p.xcd_remap) : xcd_block(p.xcd_remap)) * wg_bins;   // first bin of this workgroup
     const int we0 = blk_e0 + wid * NBW;                // first bin of this wave
     const int wnenv = max(0, min(NBW, p.E - we0));     // bins of this wave (workgroup barriers below: no early return)
     const int el = lane / G, sl = lane % G;            // this lane's bin within a group, position within the bin
