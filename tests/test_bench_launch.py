@@ -17,12 +17,25 @@ def _clean_env(**extra):
     return env
 
 
+def _communicate(cmd, env, timeout=600):
+    """Run `cmd` in a process group of its own; on a timeout the WHOLE group is killed (bench.py starts a launcher that starts the
+    ranks: killing only the child would leave grandchildren holding the pipes, and the test would wait for them for ever)."""
+    import signal
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("%r did not finish in %d s\n%s" % (cmd[-8:], timeout, err[-2000:]))
+    return p.returncode, out, err
+
+
 def _run(args, **extra):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_clean_env(**extra), cwd=ROOT,
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    rc, out, err = _communicate([sys.executable, os.path.join(ROOT, "bench.py")] + args, _clean_env(**extra))
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
 
 
@@ -124,10 +137,10 @@ def test_gpu_bench_launcher_started_ranks_time_the_reference_on_rank0():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(bench.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--only-headline", "--gpu-seconds", "0.5", "--cpu-seconds", "8"]
-    p = subprocess.run(cmd, env=_clean_env(BPP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    rc, out, err = _communicate(cmd, _clean_env(BPP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1"))
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["launcher"] == "torch.distributed.run"
     _check_multi_rank_line(d, 2)

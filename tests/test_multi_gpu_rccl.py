@@ -32,11 +32,18 @@ def _clean_env(**extra):
 
 
 def _bench(args):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_clean_env(), cwd=ROOT,
-                       capture_output=True, text=True, timeout=1200)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    import signal
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_clean_env(), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=900)
+    except subprocess.TimeoutExpired:       # kill the whole group: the launcher's ranks would otherwise keep the pipes open
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("bench.py %r did not finish\n%s" % (args, err[-2000:]))
+    assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
 
 
